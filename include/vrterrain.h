@@ -1,0 +1,234 @@
+/*
+ * vrterrain.h — C ABI of libvrterrain.so: the MI355X-native (gfx950) terrain +
+ * deferred-shading hot path of Viictor/vrenderer.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative
+ * to the reference tree).  Conventions:
+ *   - POD structs, opaque handles, `int` status (0 = VR_OK), no exceptions cross
+ *     the boundary;
+ *   - host memory is caller-owned, device memory is library-owned unless an entry
+ *     point says "device pointer";
+ *   - all GPU work is stream-ordered on the context's stream (vr_context_set_stream
+ *     takes a caller hipStream_t); nothing synchronises unless it returns host data;
+ *   - one context per device, not thread-safe per context (the reference drives the
+ *     path from one thread and one command list, Renderer.cpp:321-454).
+ *
+ * Matrices are row-major float4x4 used with ROW vectors (v' = v * M), exactly the
+ * layout of Donut's PlanarViewConstants consumed by terrain_vs.hlsl:60-61.
+ */
+#ifndef VRTERRAIN_H
+#define VRTERRAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_API __attribute__((visibility("default")))
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+    VR_OK = 0,
+    VR_ERR_INVALID_ARGUMENT = 1,
+    VR_ERR_NO_DEVICE = 2,        /* no HIP device / HIP runtime error            */
+    VR_ERR_OUT_OF_MEMORY = 3,
+    VR_ERR_TOO_MANY_INSTANCES = 4, /* select produced > max_instances nodes
+                                      (reference: assert, TerrainPass.cpp:238)   */
+    VR_ERR_OVERFLOW = 5,         /* an internal work list overflowed             */
+    VR_ERR_HIP = 6
+};
+
+/* ---- compile-time settings of the reference, as runtime fields ------------ */
+/* TerrainSettings (TerrainPass.h:23-30), QuadTree::MAX_LODS (QuadTree.h:67),
+ * minLodDistance (QuadTree.cpp:236), morph start (terrain_vs.hlsl:20). */
+#define VR_MAX_LODS 12
+
+typedef struct vr_terrain_params {
+    int32_t max_instances;    /* MAX_INSTANCES = 4096                          */
+    float   surface_size;     /* SURFACE_SIZE  = 2048 (quadtree width=height)  */
+    float   world_size;       /* WORLD_SIZE    = 2048                          */
+    int32_t grid_size;        /* GRID_SIZE     = 32 (must be 32 in this build) */
+    float   min_lod_distance; /* 4.0                                           */
+    float   morph_start;      /* 0.85                                          */
+    float   location[3];      /* quadtree centre (TerrainPass.cpp:108)         */
+    int32_t reserved;
+} vr_terrain_params;
+
+/* What the path reads from donut::engine::IView / PlanarViewConstants
+ * (terrain_vs.hlsl:46,60-61; TerrainPass.cpp:181,280-282,301-302). */
+typedef struct vr_view {
+    float   world_to_view[16];
+    float   view_to_clip[16];
+    float   world_to_clip[16];
+    float   clip_to_world[16];
+    float   camera_pos[4];      /* matViewToWorld[3] = IView::GetViewOrigin()     */
+    float   planes[6][4];       /* dm::frustum: outward normal xyz, distance w;
+                                   order NEAR, FAR, LEFT, RIGHT, TOP, BOTTOM;
+                                   a point is outside when dot(n,p) - w > 0      */
+    int32_t viewport_x, viewport_y, viewport_w, viewport_h;
+    int32_t mirrored;           /* IView::IsMirrored() -> frontCounterClockwise   */
+    int32_t reverse_depth;      /* IView::IsReverseDepth() (must be 0 here)       */
+    int32_t reserved[2];
+} vr_view;
+
+/* Donut InstanceData as filled by TerrainPass::UpdateTransforms
+ * (TerrainPass.cpp:243-253): 16-byte header + two float3x4 (row-major rows). */
+typedef struct vr_instance {
+    uint32_t padding;
+    uint32_t first_geometry_instance_index;
+    uint32_t first_geometry_index;
+    uint32_t num_geometries;
+    float    transform[12];
+    float    prev_transform[12];
+} vr_instance;
+
+/* TerrainPass::RenderParams (TerrainPass.h:68-73) + EditorParams::m_MaxHeight
+ * (Renderer.h:40, read at TerrainPass.cpp:155). */
+typedef struct vr_render_params {
+    int32_t wireframe;    /* not implemented in this round: returns INVALID_ARGUMENT */
+    int32_t lock_view;    /* reuse the previous selection (TerrainPass.cpp:173,191)  */
+    int32_t depth_only;   /* PS = null (TerrainPass.cpp:465)                         */
+    int32_t assume_cleared; /* extension: 1 = caller guarantees the G-buffer holds its
+                               clear values, so the pass need not read depth back and
+                               writes clear values itself (fuses RenderTargets::Clear,
+                               Renderer.cpp:382)                                     */
+    float   max_height;   /* EditorParams::m_MaxHeight = 400                         */
+    int32_t reserved[3];
+} vr_render_params;
+
+/* Donut LightConstants subset consumed by the deferred pass. */
+enum { VR_LIGHT_DIRECTIONAL = 1, VR_LIGHT_SPOT = 2, VR_LIGHT_POINT = 3 };
+typedef struct vr_light {
+    float   direction[3];  int32_t type;
+    float   position[3];   float   radius;            /* source radius (0 = punctual) */
+    float   color[3];      float   intensity;         /* irradiance (directional)     */
+    float   angular_size_or_inv_range;                /* radians | 1/range            */
+    float   inner_angle, outer_angle;
+    float   out_of_bounds_shadow;
+} vr_light;
+
+/* G-buffer planes (Donut GBufferRenderTargets formats; 28 B/pixel, row-major):
+ *   depth    float32                 (cleared to 1.0)
+ *   diffuse  SRGBA8_UNORM   (u32)    rgb albedo, a opacity
+ *   specular SRGBA8_UNORM   (u32)    rgb F0,     a occlusion
+ *   normals  RGBA16_SNORM   (2xu32)  xyz normal, w roughness
+ *   emissive RGBA16_FLOAT   (2xu32)  rgb emissive
+ * HDR colour: RGBA16_FLOAT (8 B/pixel, Renderer.h:69-79). */
+typedef struct vr_gbuffer_desc {
+    int32_t width, height;
+    void*   depth;     /* device pointers */
+    void*   diffuse;
+    void*   specular;
+    void*   normals;
+    void*   emissive;
+} vr_gbuffer_desc;
+
+/* Screen-tile partition of one frame over the GPUs of a node. */
+#define VR_OWNER_TILE 128
+typedef struct vr_partition {
+    int32_t rank, world_size;   /* owner(tx,ty) = (tx + ty) mod world_size        */
+} vr_partition;
+
+typedef struct vr_context  vr_context;
+typedef struct vr_terrain  vr_terrain;
+typedef struct vr_gbuffer  vr_gbuffer;
+typedef struct vr_image    vr_image;    /* RGBA16F image in device memory        */
+
+/* ---- context --------------------------------------------------------------- */
+/* nvrhi::IDevice + the single command list (main.cpp:57-61, Renderer.cpp:48). */
+VR_API int  vr_context_create(int device_ordinal, vr_context** out);
+VR_API void vr_context_destroy(vr_context* ctx);
+VR_API int  vr_context_set_stream(vr_context* ctx, void* hip_stream);
+VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submit + wait */
+VR_API const char* vr_last_error(void);
+VR_API const char* vr_version(void);
+
+/* ---- host helper: what FirstPersonCamera::LookAt + perspProjD3DStyle +
+ * PlanarView::UpdateCache produce (Renderer.cpp:97,312-319).  Pure host code. -- */
+VR_API int vr_view_from_camera(const float eye[3], const float target[3], const float up[3],
+                               float vertical_fov_radians, float z_near, float z_far,
+                               int32_t width, int32_t height, vr_view* out);
+VR_API void vr_terrain_default_params(vr_terrain_params* out);
+VR_API void vr_render_default_params(vr_render_params* out);
+
+/* ---- terrain --------------------------------------------------------------- */
+/* TerrainPass::Init + QuadTree::QuadTree/Init (TerrainPass.cpp:34-141,
+ * QuadTree.cpp:10-52).  height_r8: hm_w*hm_h bytes; albedo_srgba8: al_w*al_h*4
+ * bytes (decoded with sRGB=true, Renderer.cpp:55).  Both are copied to the device
+ * and mip chains are generated there (Donut TextureCache mip generation). */
+VR_API int  vr_terrain_create(vr_context* ctx, const vr_terrain_params* params,
+                              const uint8_t* height_r8, int32_t hm_w, int32_t hm_h,
+                              const uint8_t* albedo_srgba8, int32_t al_w, int32_t al_h,
+                              vr_terrain** out);
+VR_API void vr_terrain_destroy(vr_terrain* t);
+VR_API int  vr_terrain_num_lods(const vr_terrain* t);                 /* QuadTree::GetNumLods  */
+VR_API int  vr_terrain_lod_ranges(const vr_terrain* t, float out[VR_MAX_LODS]); /* GetLodRanges */
+
+/* QuadTree::ClearSelectedNodes + NodeSelect + TerrainPass::UpdateTransforms +
+ * EditorParams::m_NumChunks (TerrainPass.cpp:173-198, QuadTree.cpp:80-131).
+ * Runs on the device; optional host outputs (may be NULL) force a stream sync.
+ * node_ids: id = (4^d-1)/3 + iz*2^d + ix, in the reference's m_SelectedNodes order. */
+VR_API int  vr_terrain_select(vr_terrain* t, const vr_view* view, float max_height,
+                              uint32_t* node_ids, vr_instance* instances, uint32_t* count);
+
+/* TerrainPass::Render into the G-buffer framebuffer (TerrainPass.cpp:143-232;
+ * terrain_vs.hlsl, terrain_ps.hlsl; raster state TerrainPass.cpp:460-485).
+ * `part` may be NULL (= whole frame on this device). */
+VR_API int  vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev,
+                              vr_gbuffer* gb, const vr_render_params* rp,
+                              const vr_partition* part);
+/* EditorParams::m_NumChunks of the last render/select (syncs the stream). */
+VR_API int  vr_terrain_num_chunks(vr_terrain* t, uint32_t* count);
+
+/* ---- render targets ---------------------------------------------------------- */
+/* RenderTargets::Init / Clear (Renderer.h:60-101, Renderer.cpp:382). */
+VR_API int  vr_gbuffer_create(vr_context* ctx, int32_t width, int32_t height, vr_gbuffer** out);
+VR_API void vr_gbuffer_destroy(vr_gbuffer* gb);
+VR_API int  vr_gbuffer_clear(vr_gbuffer* gb);
+VR_API int  vr_gbuffer_describe(vr_gbuffer* gb, vr_gbuffer_desc* out);
+/* test/IO helpers: copy planes host<->device (synchronous). plane: 0 depth,
+ * 1 diffuse, 2 specular, 3 normals, 4 emissive. */
+VR_API int  vr_gbuffer_download(vr_gbuffer* gb, int plane, void* host, size_t bytes);
+VR_API int  vr_gbuffer_upload(vr_gbuffer* gb, int plane, const void* host, size_t bytes);
+
+/* HdrColor (Renderer.h:69-79).  external_device_mem may be NULL (library allocates)
+ * or a caller-owned device buffer of width*height*8 bytes. */
+VR_API int  vr_image_create(vr_context* ctx, int32_t width, int32_t height,
+                            void* external_device_mem, vr_image** out);
+VR_API void vr_image_destroy(vr_image* img);
+VR_API void* vr_image_device_ptr(vr_image* img);
+VR_API int  vr_image_download(vr_image* img, void* host, size_t bytes);
+
+/* ---- deferred lighting --------------------------------------------------------- */
+/* DeferredLightingPass::Render(cmd, view, Inputs{GBuffer, ambientColorTop/Bottom,
+ * lights, output}) (Renderer.cpp:417-428).  `part` NULL = whole frame, output
+ * row-major; otherwise only owned tiles are shaded and written to `hdr_out` as a
+ * packed tile-major buffer (vr_partition_packed_bytes). */
+VR_API int  vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb,
+                              const vr_light* lights, int32_t num_lights,
+                              const float ambient_top[3], const float ambient_bottom[3],
+                              vr_image* hdr_out, const vr_partition* part);
+
+/* ---- multi-GPU frame assembly (new) -------------------------------- */
+VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_partition* part,
+                                     int32_t* tiles_x, int32_t* tiles_y, int32_t* owned,
+                                     int32_t* max_owned);
+VR_API size_t vr_partition_packed_bytes(int32_t width, int32_t height, int32_t world_size);
+/* After the all-gather: gathered = world_size consecutive packed buffers (device
+ * pointer); rebuilds the row-major RGBA16F frame. */
+VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int32_t world_size,
+                              vr_image* frame_out);
+
+/* ---- synthetic inputs (media/ is absent from the reference checkout;
+ * SURVEY §8d): seeded integer-hash fBm heightmap and banded albedo, generated on
+ * the device and copied to host buffers. ------------------------------------------ */
+VR_API int vr_synth_heightmap(vr_context* ctx, int32_t size, uint32_t seed, uint8_t* out_r8);
+VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
+                           const uint8_t* height_r8, uint8_t* out_srgba8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRTERRAIN_H */

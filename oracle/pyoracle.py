@@ -1,0 +1,210 @@
+"""ctypes binding of the CPU oracle (oracle/vr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (see oracle/vr_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (vrenderer_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from vrenderer_amd.capi import (Instance, Light, Partition, RenderParams, TerrainParams, View, VR_MAX_LODS)
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "_build", "libvroracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_DIR, "vr_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _DIR, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp = C.c_void_p
+    L.orc_terrain_create.restype = vp
+    L.orc_terrain_create.argtypes = [P(TerrainParams), vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orc_terrain_destroy.argtypes = [vp]
+    L.orc_terrain_num_lods.argtypes = [vp]
+    L.orc_terrain_lod_ranges.argtypes = [vp, P(C.c_float)]
+    L.orc_terrain_num_nodes.restype = C.c_long
+    L.orc_terrain_num_nodes.argtypes = [vp]
+    L.orc_terrain_height_levels.argtypes = [vp]
+    L.orc_terrain_albedo_levels.argtypes = [vp]
+    L.orc_terrain_height_mip.restype = vp
+    L.orc_terrain_height_mip.argtypes = [vp, C.c_int, P(C.c_int), P(C.c_int)]
+    L.orc_terrain_albedo_mip.restype = vp
+    L.orc_terrain_albedo_mip.argtypes = [vp, C.c_int, P(C.c_int), P(C.c_int)]
+    L.orc_select.argtypes = [vp, P(View), C.c_float, C.c_int, vp, vp, C.c_int]
+    L.orc_set_height.argtypes = [vp]
+    L.orc_node_height.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float)]
+    L.orc_view_from_camera.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_int, P(View)]
+    L.orc_vertex.argtypes = [vp, P(View), C.c_float, P(Instance), C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
+    L.orc_gbuffer_clear.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.orc_render.argtypes = [vp, P(View), P(RenderParams), P(Partition), C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.orc_deferred.argtypes = [P(View), C.c_int, C.c_int, vp, vp, vp, vp, vp, P(Light), C.c_int,
+                               P(C.c_float), P(C.c_float), vp]
+    L.orc_deferred_f32.argtypes = L.orc_deferred.argtypes
+    L.orc_synth_heightmap.argtypes = [C.c_int, C.c_uint32, vp]
+    L.orc_synth_albedo.argtypes = [C.c_int, C.c_uint32, vp, vp]
+    L.orc_half_to_float.restype = C.c_float
+    L.orc_half_to_float.argtypes = [C.c_uint16]
+    L.orc_float_to_half.restype = C.c_uint16
+    L.orc_float_to_half.argtypes = [C.c_float]
+    L.orc_srgb8_to_linear.restype = C.c_float
+    L.orc_srgb8_to_linear.argtypes = [C.c_uint8]
+    L.orc_linear_to_srgb8.restype = C.c_uint8
+    L.orc_linear_to_srgb8.argtypes = [C.c_float]
+    L.orc_time_tree_build.restype = C.c_double
+    L.orc_time_tree_build.argtypes = [P(TerrainParams), vp, C.c_int, C.c_int]
+    L.orc_time_select.restype = C.c_double
+    L.orc_time_select.argtypes = [vp, P(View), C.c_int, C.c_float, C.c_int, P(C.c_int)]
+    L.orc_time_set_height.restype = C.c_double
+    L.orc_time_set_height.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def synth_heightmap(size, seed=1337):
+    out = np.empty((size, size), np.uint8)
+    lib().orc_synth_heightmap(size, seed, _ptr(out))
+    return out
+
+
+def synth_albedo(size, height, seed=4242):
+    out = np.empty((size, size, 4), np.uint8)
+    h = np.ascontiguousarray(height, np.uint8)
+    lib().orc_synth_albedo(size, seed, _ptr(h), _ptr(out))
+    return out
+
+
+def view_from_camera(eye, target, w, h, vfov_deg=60.0, z_near=0.1, z_far=10000.0, up=(0, 1, 0)):
+    v = View()
+    lib().orc_view_from_camera(_f3(eye), _f3(target), _f3(up), np.float32(np.radians(np.float32(vfov_deg))),
+                               z_near, z_far, w, h, C.byref(v))
+    return v
+
+
+class GBufferHost:
+    """Host G-buffer planes in the layout of vr_gbuffer_desc."""
+
+    def __init__(self, w, h):
+        self.w, self.h = w, h
+        self.depth = np.empty((h, w), np.float32)
+        self.diffuse = np.empty((h, w), np.uint32)
+        self.specular = np.empty((h, w), np.uint32)
+        self.normals = np.empty((h, w, 4), np.uint16)
+        self.emissive = np.empty((h, w, 4), np.uint16)
+        self.clear()
+
+    def clear(self):
+        lib().orc_gbuffer_clear(self.w, self.h, _ptr(self.depth), _ptr(self.diffuse), _ptr(self.specular),
+                                _ptr(self.normals), _ptr(self.emissive))
+
+    def planes(self):
+        return [self.depth, self.diffuse, self.specular, self.normals, self.emissive]
+
+
+class OracleTerrain:
+    def __init__(self, params, height, albedo):
+        self.params = params
+        self._h = np.ascontiguousarray(height, np.uint8)
+        self._a = np.ascontiguousarray(albedo, np.uint8)
+        self.handle = lib().orc_terrain_create(C.byref(params), _ptr(self._h), self._h.shape[1], self._h.shape[0],
+                                               _ptr(self._a), self._a.shape[1], self._a.shape[0])
+
+    def close(self):
+        if self.handle:
+            lib().orc_terrain_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def num_lods(self):
+        return lib().orc_terrain_num_lods(self.handle)
+
+    @property
+    def num_nodes(self):
+        return lib().orc_terrain_num_nodes(self.handle)
+
+    def lod_ranges(self):
+        out = (C.c_float * VR_MAX_LODS)()
+        lib().orc_terrain_lod_ranges(self.handle, out)
+        return np.array(out[:], np.float32)
+
+    def height_mip(self, level):
+        w, h = C.c_int(), C.c_int()
+        p = lib().orc_terrain_height_mip(self.handle, level, C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value)).copy()
+
+    def albedo_mip(self, level):
+        w, h = C.c_int(), C.c_int()
+        p = lib().orc_terrain_albedo_mip(self.handle, level, C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+
+    def height_levels(self):
+        return lib().orc_terrain_height_levels(self.handle)
+
+    def albedo_levels(self):
+        return lib().orc_terrain_albedo_levels(self.handle)
+
+    def select(self, view, max_height=400.0, stub_frustum=False, capacity=None):
+        cap = capacity or self.params.max_instances
+        ids = np.zeros(cap, np.uint32)
+        inst = (Instance * cap)()
+        n = lib().orc_select(self.handle, C.byref(view), max_height, int(stub_frustum), _ptr(ids), inst, cap)
+        m = min(n, cap)
+        return n, ids[:m].copy(), np.frombuffer(inst, dtype=np.uint8).reshape(cap, 112)[:m].copy()
+
+    def vertex(self, view, max_height, inst_bytes, vx, vz):
+        inst = Instance.from_buffer_copy(bytes(inst_bytes))
+        clip = (C.c_float * 4)()
+        world = (C.c_float * 3)()
+        lib().orc_vertex(self.handle, C.byref(view), max_height, C.byref(inst), vx, vz, clip, world)
+        return np.array(clip[:], np.float32), np.array(world[:], np.float32)
+
+    def render(self, view, gb, rp, part=None):
+        return lib().orc_render(self.handle, C.byref(view), C.byref(rp), C.byref(part) if part is not None else None,
+                                gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular),
+                                _ptr(gb.normals), _ptr(gb.emissive))
+
+
+def deferred(view, gb, lights, amb_top, amb_bottom, f32=False):
+    n = len(lights)
+    arr = (Light * max(n, 1))(*lights)
+    if f32:
+        out = np.empty((gb.h, gb.w, 4), np.float32)
+        fn = lib().orc_deferred_f32
+    else:
+        out = np.empty((gb.h, gb.w, 4), np.uint16)
+        fn = lib().orc_deferred
+    fn(C.byref(view), gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular), _ptr(gb.normals),
+       _ptr(gb.emissive), arr, n, _f3(amb_top), _f3(amb_bottom), _ptr(out))
+    return out
+
+
+def half_to_float(a):
+    return np.ascontiguousarray(a, np.uint16).view(np.float16).astype(np.float32)

@@ -1,0 +1,200 @@
+"""ctypes view of include/vrterrain.h: POD structs and the libvrterrain.so loader.
+
+The structs mirror the C header field for field; `load_library()` fails loudly when
+the HIP extension has not been built — there is no CPU fallback in the product.
+"""
+import ctypes as C
+import os
+
+VR_MAX_LODS = 12
+VR_OWNER_TILE = 128
+
+VR_OK = 0
+VR_ERR_INVALID_ARGUMENT = 1
+VR_ERR_NO_DEVICE = 2
+VR_ERR_OUT_OF_MEMORY = 3
+VR_ERR_TOO_MANY_INSTANCES = 4
+VR_ERR_OVERFLOW = 5
+VR_ERR_HIP = 6
+
+VR_LIGHT_DIRECTIONAL = 1
+VR_LIGHT_SPOT = 2
+VR_LIGHT_POINT = 3
+
+
+class TerrainParams(C.Structure):
+    _fields_ = [
+        ("max_instances", C.c_int32),
+        ("surface_size", C.c_float),
+        ("world_size", C.c_float),
+        ("grid_size", C.c_int32),
+        ("min_lod_distance", C.c_float),
+        ("morph_start", C.c_float),
+        ("location", C.c_float * 3),
+        ("reserved", C.c_int32),
+    ]
+
+
+class View(C.Structure):
+    _fields_ = [
+        ("world_to_view", C.c_float * 16),
+        ("view_to_clip", C.c_float * 16),
+        ("world_to_clip", C.c_float * 16),
+        ("clip_to_world", C.c_float * 16),
+        ("camera_pos", C.c_float * 4),
+        ("planes", (C.c_float * 4) * 6),
+        ("viewport_x", C.c_int32),
+        ("viewport_y", C.c_int32),
+        ("viewport_w", C.c_int32),
+        ("viewport_h", C.c_int32),
+        ("mirrored", C.c_int32),
+        ("reverse_depth", C.c_int32),
+        ("reserved", C.c_int32 * 2),
+    ]
+
+
+class Instance(C.Structure):
+    _fields_ = [
+        ("padding", C.c_uint32),
+        ("first_geometry_instance_index", C.c_uint32),
+        ("first_geometry_index", C.c_uint32),
+        ("num_geometries", C.c_uint32),
+        ("transform", C.c_float * 12),
+        ("prev_transform", C.c_float * 12),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("wireframe", C.c_int32),
+        ("lock_view", C.c_int32),
+        ("depth_only", C.c_int32),
+        ("assume_cleared", C.c_int32),
+        ("max_height", C.c_float),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+class Light(C.Structure):
+    _fields_ = [
+        ("direction", C.c_float * 3), ("type", C.c_int32),
+        ("position", C.c_float * 3), ("radius", C.c_float),
+        ("color", C.c_float * 3), ("intensity", C.c_float),
+        ("angular_size_or_inv_range", C.c_float),
+        ("inner_angle", C.c_float), ("outer_angle", C.c_float),
+        ("out_of_bounds_shadow", C.c_float),
+    ]
+
+
+class GBufferDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("depth", C.c_void_p), ("diffuse", C.c_void_p), ("specular", C.c_void_p),
+        ("normals", C.c_void_p), ("emissive", C.c_void_p),
+    ]
+
+
+class Partition(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world_size", C.c_int32)]
+
+
+assert C.sizeof(Instance) == 112
+assert C.sizeof(Light) == 64
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvrterrain.so")
+
+# every symbol include/vrterrain.h declares
+EXPORTS = [
+    "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_synchronize",
+    "vr_last_error", "vr_version", "vr_view_from_camera", "vr_terrain_default_params",
+    "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
+    "vr_terrain_lod_ranges", "vr_terrain_select", "vr_terrain_render", "vr_terrain_num_chunks",
+    "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
+    "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
+    "vr_image_device_ptr", "vr_image_download", "vr_deferred_light", "vr_partition_num_tiles",
+    "vr_partition_packed_bytes", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libvrterrain.so (built by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "vrenderer_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; import it first (when present) so that this
+    # process holds ONE HIP runtime: our library's NEEDED libamdhip64.so.7 then binds
+    # to the copy torch already loaded instead of pulling in /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not a requirement
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    P = C.POINTER
+    vp = C.c_void_p
+    sig = {
+        "vr_context_create": (C.c_int, [C.c_int, P(vp)]),
+        "vr_context_destroy": (None, [vp]),
+        "vr_context_set_stream": (C.c_int, [vp, vp]),
+        "vr_context_synchronize": (C.c_int, [vp]),
+        "vr_last_error": (C.c_char_p, []),
+        "vr_version": (C.c_char_p, []),
+        "vr_view_from_camera": (C.c_int, [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float, C.c_float,
+                                          C.c_float, C.c_int32, C.c_int32, P(View)]),
+        "vr_terrain_default_params": (None, [P(TerrainParams)]),
+        "vr_render_default_params": (None, [P(RenderParams)]),
+        "vr_terrain_create": (C.c_int, [vp, P(TerrainParams), vp, C.c_int32, C.c_int32, vp, C.c_int32,
+                                        C.c_int32, P(vp)]),
+        "vr_terrain_destroy": (None, [vp]),
+        "vr_terrain_num_lods": (C.c_int, [vp]),
+        "vr_terrain_lod_ranges": (C.c_int, [vp, P(C.c_float)]),
+        "vr_terrain_select": (C.c_int, [vp, P(View), C.c_float, vp, vp, P(C.c_uint32)]),
+        "vr_terrain_render": (C.c_int, [vp, P(View), P(View), vp, P(RenderParams), P(Partition)]),
+        "vr_terrain_num_chunks": (C.c_int, [vp, P(C.c_uint32)]),
+        "vr_gbuffer_create": (C.c_int, [vp, C.c_int32, C.c_int32, P(vp)]),
+        "vr_gbuffer_destroy": (None, [vp]),
+        "vr_gbuffer_clear": (C.c_int, [vp]),
+        "vr_gbuffer_describe": (C.c_int, [vp, P(GBufferDesc)]),
+        "vr_gbuffer_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+        "vr_gbuffer_upload": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+        "vr_image_create": (C.c_int, [vp, C.c_int32, C.c_int32, vp, P(vp)]),
+        "vr_image_destroy": (None, [vp]),
+        "vr_image_device_ptr": (vp, [vp]),
+        "vr_image_download": (C.c_int, [vp, vp, C.c_size_t]),
+        "vr_deferred_light": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
+                                        vp, P(Partition)]),
+        "vr_partition_num_tiles": (C.c_int, [C.c_int32, C.c_int32, P(Partition), P(C.c_int32), P(C.c_int32),
+                                             P(C.c_int32), P(C.c_int32)]),
+        "vr_partition_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+        "vr_frame_detile": (C.c_int, [vp, vp, C.c_int32, vp]),
+        "vr_synth_heightmap": (C.c_int, [vp, C.c_int32, C.c_uint32, vp]),
+        "vr_synth_albedo": (C.c_int, [vp, C.c_int32, C.c_uint32, vp, vp]),
+    }
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+class VrError(RuntimeError):
+    def __init__(self, code, where):
+        msg = ""
+        try:
+            msg = load_library().vr_last_error().decode()
+        except Exception:
+            pass
+        super().__init__(f"{where} failed with status {code}: {msg}")
+        self.code = code
+
+
+def check(code, where):
+    if code != VR_OK:
+        raise VrError(code, where)
