@@ -165,6 +165,10 @@ VR_API int  vr_terrain_create(vr_context* ctx, const vr_terrain_params* params,
 VR_API void vr_terrain_destroy(vr_terrain* t);
 VR_API int  vr_terrain_num_lods(const vr_terrain* t);                 /* QuadTree::GetNumLods  */
 VR_API int  vr_terrain_lod_ranges(const vr_terrain* t, float out[VR_MAX_LODS]); /* GetLodRanges */
+/* test/IO helper: read back one level of the device mip chain (which: 0 heightmap R8,
+ * 1 albedo SRGBA8); *w,*h receive the level size; host may be NULL to query sizes. */
+VR_API int  vr_terrain_download_mip(vr_terrain* t, int which, int level, void* host, size_t bytes,
+                                    int32_t* w, int32_t* h, int32_t* levels);
 
 /* QuadTree::ClearSelectedNodes + NodeSelect + TerrainPass::UpdateTransforms +
  * EditorParams::m_NumChunks (TerrainPass.cpp:173-198, QuadTree.cpp:80-131).

@@ -1,0 +1,290 @@
+// Deferred lighting: G-buffer (28 B/pixel) -> HdrColor RGBA16F (8 B/pixel).
+//
+// Replaces donut::render::DeferredLightingPass::Render as called at
+// Renderer.cpp:417-428 (Inputs: G-buffer, ambientColorTop/Bottom, scene lights,
+// output = HdrColor).  Donut's source is absent from the reference checkout; the
+// shading model restates its deferred_lighting_cs / ShadeSurface /
+// GGX_AnalyticalLights_times_NdotL semantics.
+//
+// This is the bandwidth kernel of the path: 36 algorithmic bytes per pixel, no
+// reuse.  Each lane owns 4 horizontally adjacent pixels so that every plane is read
+// with one or two 16-byte loads per lane (1 KiB per wave instruction) and the
+// output leaves as two 16-byte stores.  All seven loads are issued before any
+// arithmetic so a wave keeps 112 B/lane in flight.  The sRGB decode table lives in
+// LDS.  fp32 math in fixed order, no contraction: results match the CPU oracle.
+#include "vr_internal.h"
+#include "vr_tex_dev.h"
+
+#include <math.h>
+#include <string.h>
+
+struct DeferredArgs {
+    float c2w[16];
+    float cam[3];
+    float sx, sy;          // windowToClipScale = (2/W, -2/H)
+    int w, h;
+    int num_lights;
+    float amb_top[3], amb_bot[3];
+    int tiles_x;           // owner tiles per row (packed mode)
+    DevLight lights[kMaxLights];
+};
+
+#define VR_PI 3.14159265358979323846f
+#define VR_INV_PI 0.318309886183790671538f
+
+__device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
+                                            uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
+                                            float out[3])
+{
+    const float albedo[3] = { lut[diff & 255u], lut[(diff >> 8) & 255u], lut[(diff >> 16) & 255u] };
+    const float F0[3] = { lut[spec & 255u], lut[(spec >> 8) & 255u], lut[(spec >> 16) & 255u] };
+    const float occlusion = (float)(spec >> 24) / 255.0f;
+    const float N[3] = { vr_snorm16_decode(n01 & 0xffffu), vr_snorm16_decode(n01 >> 16), vr_snorm16_decode(n23 & 0xffffu) };
+    const float rough = vr_snorm16_decode(n23 >> 16);
+    const float E[3] = { vr_half_to_float(e01 & 0xffffu), vr_half_to_float(e01 >> 16), vr_half_to_float(e23 & 0xffffu) };
+
+    // ReconstructWorldPosition: window -> clip -> world
+    const float cx = ((float)px + 0.5f) * a.sx + -1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+    float wp4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wp4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + 1.0f * a.c2w[3 * 4 + j];
+    const float wp[3] = { wp4[0] / wp4[3], wp4[1] / wp4[3], wp4[2] / wp4[3] };
+    const float d[3] = { wp[0] - a.cam[0], wp[1] - a.cam[1], wp[2] - a.cam[2] };
+    const float dl = 1.0f / sqrtf(vr_dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
+    const float vi[3] = { d[0] * dl, d[1] * dl, d[2] * dl };
+    const float V[3] = { -vi[0], -vi[1], -vi[2] };
+    const float NdotVi = vr_dot3(vi[0], vi[1], vi[2], N[0], N[1], N[2]);
+    const float two = 2.0f * NdotVi;
+    const float R[3] = { vi[0] - N[0] * two, vi[1] - N[1] * two, vi[2] - N[2] * two };
+    const float NdotV = vr_saturate(vr_dot3(N[0], N[1], N[2], V[0], V[1], V[2]));
+    const float alpha = vr_max(0.01f, rough * rough);
+    const float a2 = alpha * alpha;
+    const float kk = ((rough + 1.0f) * (rough + 1.0f)) / 8.0f;
+    float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
+
+    for (int i = 0; i < a.num_lights; i++) {
+        const DevLight& Lc = a.lights[i];
+        float Lin[3], irr;
+        if (Lc.type == VR_LIGHT_DIRECTIONAL) {
+            Lin[0] = Lc.dir[0]; Lin[1] = Lc.dir[1]; Lin[2] = Lc.dir[2];
+            irr = Lc.intensity;
+        } else {
+            const float lts[3] = { wp[0] - Lc.pos[0], wp[1] - Lc.pos[1], wp[2] - Lc.pos[2] };
+            const float dist = sqrtf(vr_dot3(lts[0], lts[1], lts[2], lts[0], lts[1], lts[2]));
+            const float rd = 1.0f / dist;
+            Lin[0] = lts[0] * rd; Lin[1] = lts[1] * rd; Lin[2] = lts[2] * rd;
+            float att = 1.0f;
+            if (Lc.inv_range > 0.0f) {
+                const float q = dist * Lc.inv_range;
+                const float qq = q * q;
+                const float s = vr_saturate(1.0f - qq * qq);
+                att = s * s;
+                if (att == 0.0f) continue;
+            }
+            irr = (Lc.intensity * (rd * rd)) * att;
+        }
+        const float L[3] = { -Lin[0], -Lin[1], -Lin[2] };
+        const float NdotLd = vr_max(vr_dot3(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0f);
+        const float kd = (NdotLd * VR_INV_PI) * irr;
+        const float cosT = vr_min(vr_max(vr_dot3(R[0], R[1], R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
+        float CL[3];
+        if (cosT >= Lc.cosH) { CL[0] = R[0]; CL[1] = R[1]; CL[2] = R[2]; }
+        else {
+            const float sinT = sqrtf(vr_max(1.0f - cosT * cosT, 1e-12f));
+            const float k2 = Lc.sinH / sinT;
+            const float k1 = Lc.cosH - cosT * k2;
+#pragma unroll
+            for (int c = 0; c < 3; c++) CL[c] = L[c] * k1 + R[c] * k2;
+        }
+        float Hv[3] = { CL[0] + V[0], CL[1] + V[1], CL[2] + V[2] };
+        const float hl2 = vr_dot3(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
+        const float hs = hl2 > 0.0f ? 1.0f / sqrtf(hl2) : 0.0f;
+        Hv[0] *= hs; Hv[1] *= hs; Hv[2] *= hs;
+        const float NdotH = vr_saturate(vr_dot3(N[0], N[1], N[2], Hv[0], Hv[1], Hv[2]));
+        const float NdotL = vr_saturate(vr_dot3(N[0], N[1], N[2], CL[0], CL[1], CL[2]));
+        const float VdotH = vr_saturate(vr_dot3(V[0], V[1], V[2], Hv[0], Hv[1], Hv[2]));
+        const float corrAlpha = vr_saturate(alpha + 0.5f * Lc.tanH);
+        float sn = alpha / corrAlpha; sn = sn * sn;
+        const float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+        const float D = (a2 / (VR_PI * (dd * dd))) * sn;
+        const float G = 1.0f / ((NdotL * (1.0f - kk) + kk) * (NdotV * (1.0f - kk) + kk));
+        const float om = 1.0f - VdotH;
+        const float om2 = om * om;
+        const float fw = (om2 * om2) * om;
+        const float ks = (((D * G) * NdotL) / 4.0f) * irr;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float F = F0[c] + (1.0f - F0[c]) * fw;
+            diffuseTerm[c] = diffuseTerm[c] + (albedo[c] * kd) * Lc.color[c];
+            specularTerm[c] = specularTerm[c] + (F * ks) * Lc.color[c];
+        }
+    }
+    const float tt = N[1] * 0.5f + 0.5f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float amb = a.amb_bot[c] + (a.amb_top[c] - a.amb_bot[c]) * tt;
+        diffuseTerm[c] = diffuseTerm[c] + (amb * albedo[c]) * occlusion;
+        specularTerm[c] = specularTerm[c] + (amb * F0[c]) * occlusion;
+        out[c] = (diffuseTerm[c] + specularTerm[c]) + E[c];
+    }
+}
+
+// PACKED = false: whole frame, row-major output; one lane = 4 consecutive pixels.
+// PACKED = true : only owner tiles of this rank, output packed tile-major
+//                 [local tile][128 rows][128 px]; block = 8 rows x 128 px of a tile.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
+                                                   const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
+                                                   const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
+                                                   uint2* __restrict__ out, const float* __restrict__ lut_g,
+                                                   const int32_t* __restrict__ owned_tiles)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+
+    int px0, py;          // first pixel of this lane's quad
+    size_t out_index;     // in pixels
+    if (PACKED) {
+        const int lt = blockIdx.x >> 4, rg = blockIdx.x & 15;
+        const int tile = owned_tiles[lt];
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int row = rg * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 4;
+        px0 = tx * VR_OWNER_TILE + col; py = ty * VR_OWNER_TILE + row;
+        out_index = ((size_t)lt * VR_OWNER_TILE + row) * VR_OWNER_TILE + col;
+        if (px0 >= a.w || py >= a.h) return;
+    } else {
+        const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t p = q * 4;
+        if (p >= (size_t)a.w * a.h) return;
+        py = (int)(p / (size_t)a.w); px0 = (int)(p - (size_t)py * a.w);
+        out_index = p;
+    }
+    const size_t p = (size_t)py * a.w + px0;
+    // issue every load first: 7 x 16 B per lane in flight
+    const float4 dz = *reinterpret_cast<const float4*>(g_depth + p);
+    const uint4 df = *reinterpret_cast<const uint4*>(g_diff + p);
+    const uint4 sp = *reinterpret_cast<const uint4*>(g_spec + p);
+    const uint4 n0 = *reinterpret_cast<const uint4*>(g_nrm + p);
+    const uint4 n1 = *reinterpret_cast<const uint4*>(g_nrm + p + 2);
+    const uint4 e0 = *reinterpret_cast<const uint4*>(g_emi + p);
+    const uint4 e1 = *reinterpret_cast<const uint4*>(g_emi + p + 2);
+
+    const float depth[4] = { dz.x, dz.y, dz.z, dz.w };
+    const uint32_t dfa[4] = { df.x, df.y, df.z, df.w }, spa[4] = { sp.x, sp.y, sp.z, sp.w };
+    const uint32_t na[8] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w };
+    const uint32_t ea[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float rgb[3];
+        shade_pixel(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb);
+        o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
+        o[2 * k + 1] = vr_float_to_half(rgb[2]);          // alpha = 0
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + out_index);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// Generic fallback for widths that are not a multiple of 4: one pixel per lane.
+__global__ __launch_bounds__(256) void k_deferred_scalar(DeferredArgs a, const float* __restrict__ g_depth,
+                                                          const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
+                                                          const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
+                                                          uint2* __restrict__ out, const float* __restrict__ lut_g)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)a.w * a.h) return;
+    const int py = (int)(p / (size_t)a.w), px = (int)(p - (size_t)py * a.w);
+    const uint2 n = g_nrm[p], e = g_emi[p];
+    float rgb[3];
+    shade_pixel(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb);
+    out[p] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
+}
+
+extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
+                                         int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
+                                         vr_image* hdr, const vr_partition* part)
+{
+    VR_REQUIRE(ctx && view && gb && hdr && amb_top && amb_bottom, "NULL argument");
+    VR_REQUIRE(num_lights >= 0 && num_lights <= kMaxLights, "at most 16 lights (terrain_cb.h:15)");
+    VR_REQUIRE(num_lights == 0 || lights, "lights is NULL");
+    VR_REQUIRE(view->viewport_w == gb->w && view->viewport_h == gb->h && view->viewport_x == 0 && view->viewport_y == 0,
+               "view viewport must cover the G-buffer");
+    VR_HIP(hipSetDevice(ctx->device));
+    DeferredArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 16; i++) a.c2w[i] = view->clip_to_world[i];
+    for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
+    a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h;
+    a.num_lights = num_lights;
+    for (int i = 0; i < num_lights; i++) {
+        const vr_light& l = lights[i];
+        VR_REQUIRE(l.type == VR_LIGHT_DIRECTIONAL || l.type == VR_LIGHT_POINT, "only directional and point lights are supported");
+        VR_REQUIRE(l.type != VR_LIGHT_POINT || l.radius == 0.0f, "point lights must be punctual (radius 0)");
+        DevLight& d = a.lights[i];
+        for (int k = 0; k < 3; k++) { d.dir[k] = l.direction[k]; d.pos[k] = l.position[k]; d.color[k] = l.color[k]; }
+        d.type = l.type; d.intensity = l.intensity;
+        d.inv_range = l.type == VR_LIGHT_POINT ? l.angular_size_or_inv_range : 0.0f;
+        const double half = l.type == VR_LIGHT_DIRECTIONAL ? 0.5 * (double)l.angular_size_or_inv_range : 0.0;
+        d.cosH = (float)cos(half); d.sinH = (float)sin(half); d.tanH = (float)tan(half); d.pad = 0.0f;
+    }
+    const size_t npx = (size_t)gb->w * gb->h;
+    const bool packed = part && part->world_size > 1;
+    if (packed) {
+        int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
+        if (rc) return rc;
+        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 8 <= hdr->capacity_bytes,
+                   "hdr_out is smaller than vr_partition_packed_bytes()");
+        VR_REQUIRE(gb->w % 4 == 0, "partitioned frames need a width that is a multiple of 4");
+        a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+        if (ctx->num_owned > 0)
+            hipLaunchKernelGGL(k_deferred<true>, dim3((unsigned)ctx->num_owned * 16), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles);
+    } else {
+        VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
+        if (gb->w % 4 == 0) {
+            const size_t quads = npx / 4;
+            hipLaunchKernelGGL(k_deferred<false>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr);
+        } else {
+            hipLaunchKernelGGL(k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut);
+        }
+    }
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}
+
+// ---- frame assembly after the all-gather ------------------------------------
+// gathered = world_size packed buffers back to back; one lane copies 2 pixels (16 B).
+__global__ __launch_bounds__(256) void k_detile(const uint4* __restrict__ gathered, uint4* __restrict__ frame, int w, int h,
+                                                 int tiles_x, const int32_t* __restrict__ tile_slot)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // pixel pair index
+    const size_t p = i * 2;
+    if (p >= (size_t)w * h) return;
+    const int y = (int)(p / (size_t)w), x = (int)(p - (size_t)y * w);
+    const int tx = x / VR_OWNER_TILE, ty = y / VR_OWNER_TILE;
+    const int slot = tile_slot[ty * tiles_x + tx];
+    const size_t src = ((size_t)slot * VR_OWNER_TILE + (y - ty * VR_OWNER_TILE)) * VR_OWNER_TILE + (x - tx * VR_OWNER_TILE);
+    frame[i] = gathered[src / 2];
+}
+
+extern "C" VR_API int vr_frame_detile(vr_context* ctx, const void* gathered, int32_t world, vr_image* frame)
+{
+    VR_REQUIRE(ctx && gathered && frame, "NULL argument");
+    VR_REQUIRE(ctx->part_world == world && ctx->part_w == frame->w && ctx->part_h == frame->h,
+               "vr_frame_detile must follow vr_deferred_light with the same partition and frame size");
+    VR_REQUIRE(frame->w % 2 == 0, "frame width must be even");
+    VR_HIP(hipSetDevice(ctx->device));
+    const size_t pairs = (size_t)frame->w * frame->h / 2;
+    const int tiles_x = (frame->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+    hipLaunchKernelGGL(k_detile, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)gathered,
+                       (uint4*)frame->data, frame->w, frame->h, tiles_x, ctx->d_tile_slot);
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}

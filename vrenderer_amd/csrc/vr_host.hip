@@ -1,0 +1,373 @@
+// Host side of libvrterrain.so: context, render targets, view helper, partition tables.
+#include "vr_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---- errors ---------------------------------------------------------------------
+static thread_local char g_last_error[512] = "";
+void vr_set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+extern "C" VR_API const char* vr_last_error(void) { return g_last_error; }
+extern "C" VR_API const char* vr_version(void) { return "vrterrain 0.1 (gfx950)"; }
+
+// ---- sRGB tables (SRGBA8 fetch / render-target conversion) -------------------------
+static double srgb_eotf(double c) { return c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4); }
+
+// ---- context ----------------------------------------------------------------------
+extern "C" VR_API int vr_context_create(int device, vr_context** out)
+{
+    VR_REQUIRE(out != nullptr, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { vr_set_error("no HIP device available (%s)", hipGetErrorString(e)); return VR_ERR_NO_DEVICE; }
+    VR_REQUIRE(device >= 0 && device < n, "device ordinal out of range");
+    VR_HIP(hipSetDevice(device));
+    vr_context* c = new vr_context();
+    c->device = device;
+    c->stream = nullptr;   // default stream until vr_context_set_stream
+    for (int i = 0; i < 256; i++) c->h_srgb_lut[i] = (float)srgb_eotf((double)i / 255.0);
+    c->h_srgb_thr[0] = 0.0f;
+    for (int k = 1; k < 256; k++) c->h_srgb_thr[k] = (float)srgb_eotf(((double)k - 0.5) / 255.0);
+    VR_HIP(hipMalloc(&c->d_srgb_lut, 256 * sizeof(float)));
+    VR_HIP(hipMalloc(&c->d_srgb_thr, 256 * sizeof(float)));
+    VR_HIP(hipMemcpy(c->d_srgb_lut, c->h_srgb_lut, 256 * sizeof(float), hipMemcpyHostToDevice));
+    VR_HIP(hipMemcpy(c->d_srgb_thr, c->h_srgb_thr, 256 * sizeof(float), hipMemcpyHostToDevice));
+    *out = c;
+    return VR_OK;
+}
+
+extern "C" VR_API void vr_context_destroy(vr_context* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr);
+    (void)hipFree(c->d_owned_tiles); (void)hipFree(c->d_tile_slot); (void)hipFree(c->d_raster_tiles);
+    delete c;
+}
+
+extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
+{
+    VR_REQUIRE(c != nullptr, "ctx is NULL");
+    c->stream = (hipStream_t)s;
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_context_synchronize(vr_context* c)
+{
+    VR_REQUIRE(c != nullptr, "ctx is NULL");
+    VR_HIP(hipStreamSynchronize(c->stream));
+    return VR_OK;
+}
+
+// ---- defaults (TerrainPass.h:23-30, QuadTree.cpp:236, terrain_vs.hlsl:20, Renderer.h:40) ----
+extern "C" VR_API void vr_terrain_default_params(vr_terrain_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->max_instances = 4096; p->surface_size = 2048.0f; p->world_size = 2048.0f; p->grid_size = 32;
+    p->min_lod_distance = 4.0f; p->morph_start = 0.85f;
+}
+extern "C" VR_API void vr_render_default_params(vr_render_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->max_height = 400.0f;
+}
+
+// ---- view helper -------------------------------------------------------------------
+// What the caller's Donut objects produce (source absent from the reference checkout,
+// restated): FirstPersonCamera::LookAt (Renderer.cpp:97), perspProjD3DStyle
+// (Renderer.cpp:315), PlanarView::UpdateCache -> view frustum (TerrainPass.cpp:181).
+namespace {
+struct V3 { float x, y, z; };
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline V3 normalized(V3 v) { float l = sqrtf(dot(v, v)); if (l > 0.0f) { v.x /= l; v.y /= l; v.z /= l; } return v; }
+
+void plane_from(float out[4], float x, float y, float z, float d)
+{
+    float l2 = dot({ x, y, z }, { x, y, z });
+    float s = l2 > 0.0f ? 1.0f / sqrtf(l2) : 0.0f;
+    out[0] = x * s; out[1] = y * s; out[2] = z * s; out[3] = d * s;
+}
+
+bool invert4x4(const float m[16], float out[16])
+{
+    double a[4][8];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; c++) {
+        int piv = c; double best = fabs(a[c][c]);
+        for (int r = c + 1; r < 4; r++) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+        if (best == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; j++) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+        double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 8; j++) a[c][j] *= inv;
+        for (int r = 0; r < 4; r++) if (r != c) { double f = a[r][c]; if (f != 0.0) for (int j = 0; j < 8; j++) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[i * 4 + j] = (float)a[i][j + 4];
+    return true;
+}
+} // namespace
+
+extern "C" VR_API int vr_view_from_camera(const float eye[3], const float target[3], const float up_in[3],
+                                           float vfov, float z_near, float z_far, int32_t w, int32_t h, vr_view* o)
+{
+    VR_REQUIRE(eye && target && up_in && o, "NULL argument");
+    VR_REQUIRE(w > 0 && h > 0 && z_far > z_near && z_near > 0.0f, "bad projection parameters");
+    memset(o, 0, sizeof(*o));
+    V3 dir = normalized({ target[0] - eye[0], target[1] - eye[1], target[2] - eye[2] });
+    V3 up = normalized({ up_in[0], up_in[1], up_in[2] });
+    V3 right = normalized(cross(dir, up));
+    up = normalized(cross(right, dir));
+    const V3 axes[3] = { right, up, dir };
+    float* m = o->world_to_view;
+    const float r3[3] = { right.x, right.y, right.z }, u3[3] = { up.x, up.y, up.z }, d3[3] = { dir.x, dir.y, dir.z };
+    for (int i = 0; i < 3; i++) { m[i * 4 + 0] = r3[i]; m[i * 4 + 1] = u3[i]; m[i * 4 + 2] = d3[i]; m[i * 4 + 3] = 0.0f; }
+    V3 ne = { -eye[0], -eye[1], -eye[2] };
+    for (int j = 0; j < 3; j++) m[12 + j] = dot(ne, axes[j]);
+    m[15] = 1.0f;
+    float ys = 1.0f / tanf(0.5f * vfov), xs = ys / ((float)w / (float)h), zs = 1.0f / (z_far - z_near);
+    float* p = o->view_to_clip;
+    p[0] = xs; p[5] = ys; p[10] = z_far * zs; p[11] = 1.0f; p[14] = -z_near * z_far * zs;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++)
+        o->world_to_clip[i * 4 + j] = ((m[i * 4 + 0] * p[0 * 4 + j] + m[i * 4 + 1] * p[1 * 4 + j]) + m[i * 4 + 2] * p[2 * 4 + j]) + m[i * 4 + 3] * p[3 * 4 + j];
+    if (!invert4x4(o->world_to_clip, o->clip_to_world)) { vr_set_error("singular view-projection"); return VR_ERR_INVALID_ARGUMENT; }
+    o->camera_pos[0] = eye[0]; o->camera_pos[1] = eye[1]; o->camera_pos[2] = eye[2]; o->camera_pos[3] = 1.0f;
+    const float* c = o->world_to_clip;
+    plane_from(o->planes[0], -c[2], -c[6], -c[10], c[14]);
+    plane_from(o->planes[1], -c[3] + c[2], -c[7] + c[6], -c[11] + c[10], c[15] - c[14]);
+    plane_from(o->planes[2], -c[3] - c[0], -c[7] - c[4], -c[11] - c[8], c[15] + c[12]);
+    plane_from(o->planes[3], -c[3] + c[0], -c[7] + c[4], -c[11] + c[8], c[15] - c[12]);
+    plane_from(o->planes[4], -c[3] + c[1], -c[7] + c[5], -c[11] + c[9], c[15] - c[13]);
+    plane_from(o->planes[5], -c[3] - c[1], -c[7] - c[5], -c[11] - c[9], c[15] + c[13]);
+    o->viewport_x = 0; o->viewport_y = 0; o->viewport_w = w; o->viewport_h = h;
+    float det = right.x * (up.y * dir.z - up.z * dir.y) - up.x * (right.y * dir.z - right.z * dir.y)
+              + dir.x * (right.y * up.z - right.z * up.y);
+    o->mirrored = det < 0.0f ? 1 : 0;
+    o->reverse_depth = 0;
+    return VR_OK;
+}
+
+// ---- G-buffer (RenderTargets::Init / Clear; Renderer.h:60-101, Renderer.cpp:382) --------
+extern "C" VR_API int vr_gbuffer_create(vr_context* ctx, int32_t w, int32_t h, vr_gbuffer** out)
+{
+    VR_REQUIRE(ctx && out, "NULL argument");
+    VR_REQUIRE(w > 0 && h > 0 && w <= 16384 && h <= 16384, "G-buffer size out of range");
+    VR_HIP(hipSetDevice(ctx->device));
+    vr_gbuffer* g = new vr_gbuffer();
+    g->ctx = ctx; g->w = w; g->h = h;
+    size_t n = (size_t)w * h;
+    // one allocation, planes 256-byte aligned (28 B/pixel)
+    size_t a = 256;
+    size_t o_depth = 0, o_diff = (o_depth + n * 4 + a - 1) / a * a, o_spec = (o_diff + n * 4 + a - 1) / a * a;
+    size_t o_nrm = (o_spec + n * 4 + a - 1) / a * a, o_emi = (o_nrm + n * 8 + a - 1) / a * a, total = o_emi + n * 8;
+    uint8_t* base = nullptr;
+    hipError_t e = hipMalloc(&base, total);
+    if (e != hipSuccess) { delete g; vr_set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); return VR_ERR_OUT_OF_MEMORY; }
+    g->depth = (float*)(base + o_depth); g->diffuse = (uint32_t*)(base + o_diff); g->specular = (uint32_t*)(base + o_spec);
+    g->normals = (uint2*)(base + o_nrm); g->emissive = (uint2*)(base + o_emi);
+    *out = g;
+    return vr_gbuffer_clear(g);
+}
+
+extern "C" VR_API void vr_gbuffer_destroy(vr_gbuffer* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipFree(g->depth);   // base of the single allocation
+    delete g;
+}
+
+__global__ void k_fill_u32x4(uint4* p, size_t n4, uint32_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint4 val = make_uint4(v, v, v, v);
+    for (; i < n4; i += stride) p[i] = val;
+}
+__global__ void k_fill_u32_tail(uint32_t* p, size_t begin, size_t n, uint32_t v)
+{
+    size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static int fill_u32(hipStream_t s, void* ptr, size_t count, uint32_t v)
+{
+    size_t n4 = count / 4;
+    if (n4) {
+        size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_fill_u32x4, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)ptr, n4, v);
+    }
+    if (count > n4 * 4) hipLaunchKernelGGL(k_fill_u32_tail, dim3(1), dim3(64), 0, s, (uint32_t*)ptr, n4 * 4, count, v);
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
+{
+    VR_REQUIRE(g != nullptr, "gbuffer is NULL");
+    VR_HIP(hipSetDevice(g->ctx->device));
+    size_t n = (size_t)g->w * g->h;
+    hipStream_t s = g->ctx->stream;
+    int rc;
+    if ((rc = fill_u32(s, g->depth, n, 0x3f800000u))) return rc;      // depth = 1.0 (non-reversed)
+    if ((rc = fill_u32(s, g->diffuse, n, 0u))) return rc;
+    if ((rc = fill_u32(s, g->specular, n, 0u))) return rc;
+    if ((rc = fill_u32(s, g->normals, n * 2, 0u))) return rc;
+    if ((rc = fill_u32(s, g->emissive, n * 2, 0u))) return rc;
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_gbuffer_describe(vr_gbuffer* g, vr_gbuffer_desc* d)
+{
+    VR_REQUIRE(g && d, "NULL argument");
+    d->width = g->w; d->height = g->h; d->depth = g->depth; d->diffuse = g->diffuse; d->specular = g->specular;
+    d->normals = g->normals; d->emissive = g->emissive;
+    return VR_OK;
+}
+
+static int plane_info(vr_gbuffer* g, int plane, void** ptr, size_t* bytes)
+{
+    size_t n = (size_t)g->w * g->h;
+    switch (plane) {
+    case 0: *ptr = g->depth; *bytes = n * 4; return VR_OK;
+    case 1: *ptr = g->diffuse; *bytes = n * 4; return VR_OK;
+    case 2: *ptr = g->specular; *bytes = n * 4; return VR_OK;
+    case 3: *ptr = g->normals; *bytes = n * 8; return VR_OK;
+    case 4: *ptr = g->emissive; *bytes = n * 8; return VR_OK;
+    }
+    vr_set_error("bad plane index %d", plane);
+    return VR_ERR_INVALID_ARGUMENT;
+}
+extern "C" VR_API int vr_gbuffer_download(vr_gbuffer* g, int plane, void* host, size_t bytes)
+{
+    VR_REQUIRE(g && host, "NULL argument");
+    void* p; size_t nb; int rc = plane_info(g, plane, &p, &nb); if (rc) return rc;
+    VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
+    VR_HIP(hipSetDevice(g->ctx->device));
+    VR_HIP(hipMemcpyAsync(host, p, nb, hipMemcpyDeviceToHost, g->ctx->stream));
+    VR_HIP(hipStreamSynchronize(g->ctx->stream));
+    return VR_OK;
+}
+extern "C" VR_API int vr_gbuffer_upload(vr_gbuffer* g, int plane, const void* host, size_t bytes)
+{
+    VR_REQUIRE(g && host, "NULL argument");
+    void* p; size_t nb; int rc = plane_info(g, plane, &p, &nb); if (rc) return rc;
+    VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
+    VR_HIP(hipSetDevice(g->ctx->device));
+    VR_HIP(hipMemcpyAsync(p, host, nb, hipMemcpyHostToDevice, g->ctx->stream));
+    VR_HIP(hipStreamSynchronize(g->ctx->stream));
+    return VR_OK;
+}
+
+// ---- HDR image -------------------------------------------------------------------
+extern "C" VR_API int vr_image_create(vr_context* ctx, int32_t w, int32_t h, void* external, vr_image** out)
+{
+    VR_REQUIRE(ctx && out, "NULL argument");
+    VR_REQUIRE(w > 0 && h > 0, "bad image size");
+    VR_HIP(hipSetDevice(ctx->device));
+    vr_image* im = new vr_image();
+    im->ctx = ctx; im->w = w; im->h = h; im->owned = (external == nullptr);
+    im->capacity_bytes = (size_t)w * h * 8;
+    if (external) im->data = external;
+    else {
+        hipError_t e = hipMalloc(&im->data, im->capacity_bytes);
+        if (e != hipSuccess) { delete im; vr_set_error("hipMalloc(%zu) failed", (size_t)w * h * 8); return VR_ERR_OUT_OF_MEMORY; }
+    }
+    *out = im;
+    return VR_OK;
+}
+extern "C" VR_API void vr_image_destroy(vr_image* im)
+{
+    if (!im) return;
+    if (im->owned) { (void)hipSetDevice(im->ctx->device); (void)hipFree(im->data); }
+    delete im;
+}
+extern "C" VR_API void* vr_image_device_ptr(vr_image* im) { return im ? im->data : nullptr; }
+extern "C" VR_API int vr_image_download(vr_image* im, void* host, size_t bytes)
+{
+    VR_REQUIRE(im && host, "NULL argument");
+    VR_REQUIRE(bytes <= im->capacity_bytes, "byte count exceeds the image");
+    VR_HIP(hipSetDevice(im->ctx->device));
+    VR_HIP(hipMemcpyAsync(host, im->data, bytes, hipMemcpyDeviceToHost, im->ctx->stream));
+    VR_HIP(hipStreamSynchronize(im->ctx->stream));
+    return VR_OK;
+}
+
+// ---- screen-tile partition ----------------------------------------------
+static void owner_grid(int w, int h, int* tx, int* ty)
+{
+    *tx = (w + VR_OWNER_TILE - 1) / VR_OWNER_TILE; *ty = (h + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+}
+static int count_owned(int tx, int ty, int rank, int world)
+{
+    int n = 0;
+    for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++) n += ((x + y) % world) == rank;
+    return n;
+}
+
+extern "C" VR_API int vr_partition_num_tiles(int32_t w, int32_t h, const vr_partition* part, int32_t* tiles_x,
+                                              int32_t* tiles_y, int32_t* owned, int32_t* max_owned)
+{
+    VR_REQUIRE(w > 0 && h > 0, "bad frame size");
+    int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
+    VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
+    int tx, ty; owner_grid(w, h, &tx, &ty);
+    if (tiles_x) *tiles_x = tx;
+    if (tiles_y) *tiles_y = ty;
+    if (owned) *owned = count_owned(tx, ty, rank, world);
+    if (max_owned) { int m = 0; for (int r = 0; r < world; r++) { int c = count_owned(tx, ty, r, world); if (c > m) m = c; } *max_owned = m; }
+    return VR_OK;
+}
+
+extern "C" VR_API size_t vr_partition_packed_bytes(int32_t w, int32_t h, int32_t world)
+{
+    if (w <= 0 || h <= 0 || world < 1) return 0;
+    vr_partition p = { 0, world };
+    int32_t mo = 0;
+    vr_partition_num_tiles(w, h, &p, nullptr, nullptr, nullptr, &mo);
+    return (size_t)mo * VR_OWNER_TILE * VR_OWNER_TILE * 8;
+}
+
+int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part)
+{
+    int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
+    VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
+    if (ctx->part_w == w && ctx->part_h == h && ctx->part_rank == rank && ctx->part_world == world) return VR_OK;
+    VR_HIP(hipSetDevice(ctx->device));
+    int tx, ty; owner_grid(w, h, &tx, &ty);
+    int max_owned = 0;
+    for (int r = 0; r < world; r++) { int c = count_owned(tx, ty, r, world); if (c > max_owned) max_owned = c; }
+    std::vector<int32_t> owned, slot((size_t)tx * ty), raster;
+    std::vector<int> next(world, 0);
+    const int rtx = (w + kRasterTile - 1) / kRasterTile, rty = (h + kRasterTile - 1) / kRasterTile;
+    const int sub = VR_OWNER_TILE / kRasterTile;
+    for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++) {
+        int o = (x + y) % world;
+        slot[(size_t)y * tx + x] = o * max_owned + next[o]++;
+        if (o == rank) {
+            owned.push_back(y * tx + x);
+            for (int sy = 0; sy < sub; sy++) for (int sx = 0; sx < sub; sx++) {
+                int rx = x * sub + sx, ry = y * sub + sy;
+                if (rx < rtx && ry < rty) raster.push_back(ry * rtx + rx);
+            }
+        }
+    }
+    // The partition tables may still be in use by kernels in flight on the stream.
+    VR_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_owned_tiles); (void)hipFree(ctx->d_tile_slot); (void)hipFree(ctx->d_raster_tiles);
+    ctx->d_owned_tiles = ctx->d_tile_slot = ctx->d_raster_tiles = nullptr;
+    VR_HIP(hipMalloc(&ctx->d_owned_tiles, sizeof(int32_t) * (owned.size() + 1)));
+    VR_HIP(hipMalloc(&ctx->d_tile_slot, sizeof(int32_t) * slot.size()));
+    VR_HIP(hipMalloc(&ctx->d_raster_tiles, sizeof(int32_t) * (raster.size() + 1)));
+    if (!owned.empty()) VR_HIP(hipMemcpy(ctx->d_owned_tiles, owned.data(), sizeof(int32_t) * owned.size(), hipMemcpyHostToDevice));
+    VR_HIP(hipMemcpy(ctx->d_tile_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice));
+    if (!raster.empty()) VR_HIP(hipMemcpy(ctx->d_raster_tiles, raster.data(), sizeof(int32_t) * raster.size(), hipMemcpyHostToDevice));
+    ctx->num_owned = (int)owned.size(); ctx->max_owned = max_owned; ctx->num_raster_tiles = (int)raster.size();
+    ctx->part_w = w; ctx->part_h = h; ctx->part_rank = rank; ctx->part_world = world;
+    return VR_OK;
+}

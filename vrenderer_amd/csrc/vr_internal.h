@@ -1,0 +1,137 @@
+// Internal declarations shared by the translation units of libvrterrain.so.
+// gfx950 (MI355X) only; wave = 64 lanes everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vrterrain.h"
+
+// ---- error plumbing -------------------------------------------------------------
+void vr_set_error(const char* fmt, ...);
+#define VR_HIP(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            vr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return e__ == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP;    \
+        }                                                                             \
+    } while (0)
+#define VR_REQUIRE(cond, msg)                                                         \
+    do { if (!(cond)) { vr_set_error("%s:%d: %s", __FILE__, __LINE__, msg); return VR_ERR_INVALID_ARGUMENT; } } while (0)
+
+// ---- geometry constants -----------------------------------------------------------
+constexpr int kGrid = 32;                    // GRID_SIZE (TerrainPass.h:28)
+constexpr int kSide = kGrid + 1;             // 33 vertices per side
+constexpr int kVertsPerInst = kSide * kSide; // 1089
+constexpr int kTrisPerInst = kGrid * kGrid * 2; // 2048
+constexpr int kRasterTile = 64;              // raster/bin tile (pixels)
+constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
+constexpr int kMaxLevels = 16;
+constexpr float kGuardBand = 100.0f;
+
+// Mip chain in device memory, passed to kernels by value.
+struct DevTex {
+    const uint8_t* base;        // level 0 first, then the coarser levels
+    const uint32_t* off;        // device table: byte offset of each level (kMaxLevels entries)
+    int levels;
+    int w0, h0;                 // level l is max(1, w0 >> l) x max(1, h0 >> l)
+    int pad;
+};
+
+// Per-light constants the deferred kernel reads (host precomputes the half-angle terms).
+struct DevLight {
+    float dir[3];  int type;
+    float pos[3];  float inv_range;
+    float color[3]; float intensity;
+    float cosH, sinH, tanH, pad;
+};
+
+// Transformed vertex: clip position, world xz and the snapped screen vertex.
+struct DevVert {
+    float cx, cy, cz, cw;
+    float wx, wz;
+    int32_t X, Y;      // 24.8 fixed point, valid when cw > 0
+    float z, iw;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(DevVert) == 48, "DevVert layout");
+
+// Explicit triangle (output of the clipper for triangles that cross the near plane
+// or leave the guard band): indices into the vertex array's extra region, the
+// draw-order key and the raster-tile rectangle it touches.
+struct HardTriRec { uint32_t v0, v1, v2, order_key; uint32_t rect_lo, rect_hi, pad0, pad1; };
+static_assert(sizeof(HardTriRec) == 32, "HardTriRec layout");
+
+struct vr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* d_srgb_lut = nullptr;   // 256 floats: sRGB8 -> linear
+    float* d_srgb_thr = nullptr;   // 256 floats: encode thresholds
+    float h_srgb_lut[256];
+    float h_srgb_thr[256];
+    // cached partition tables (device), rebuilt when (w,h,rank,world) changes
+    int part_w = 0, part_h = 0, part_rank = -1, part_world = 0;
+    int32_t* d_owned_tiles = nullptr;   // owner-tile ids (128x128) owned by this rank
+    int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
+    int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64) inside owned owner tiles
+    int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+};
+
+struct vr_gbuffer {
+    vr_context* ctx;
+    int w, h;
+    float* depth; uint32_t* diffuse; uint32_t* specular; uint2* normals; uint2* emissive;
+};
+
+struct vr_image {
+    vr_context* ctx;
+    int w, h;
+    void* data;
+    bool owned;
+    size_t capacity_bytes;
+};
+
+struct vr_terrain {
+    vr_context* ctx;
+    vr_terrain_params p;
+    int num_lods;
+    float lod_ranges[VR_MAX_LODS];
+    DevTex height, albedo;
+    uint8_t* d_height = nullptr; uint8_t* d_albedo = nullptr;
+    // select outputs (device)
+    uint32_t* d_node_ids = nullptr;
+    vr_instance* d_instances = nullptr;
+    uint32_t* d_counters = nullptr;     // [0] selected count, [1] status flags, [2] hard tris, [3] hard verts, ...
+    // raster scratch (device), sized for max_instances
+    DevVert* d_verts = nullptr;         // max_instances*1089 regular + extra (clipper) region
+    uint32_t extra_vert_cap = 0, hard_cap = 0;
+    uint64_t* d_rect = nullptr;         // per triangle: tile rect or ~0 when culled
+    uint32_t* d_hard_list = nullptr;    // triangle ids that need the clipper
+    HardTriRec* d_hard_tris = nullptr;  // capacity hard_cap * 4
+    uint32_t* d_hard_first = nullptr;   // per regular triangle id: first HardTri index
+    uint32_t* d_tile_count = nullptr;   // per raster tile
+    uint32_t* d_tile_offset = nullptr;
+    uint32_t* d_tile_cursor = nullptr;
+    uint32_t* d_bin_entries = nullptr;
+    size_t bin_capacity = 0;
+    int scratch_tiles = 0;
+    bool have_selection = false;
+};
+
+// ---- cross-TU entry points ----------------------------------------------------------
+int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
+                          DevTex* out, uint8_t** out_mem);
+int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height);
+int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part);
+
+// ---- device helpers shared by kernels ---------------------------------------------------
+__device__ __forceinline__ float vr_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float vr_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float vr_saturate(float x) { return vr_min(vr_max(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float vr_dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}

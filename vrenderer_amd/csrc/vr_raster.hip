@@ -1,0 +1,710 @@
+// TerrainPass::Render as compute: vertex transform (terrain_vs.hlsl), triangle
+// setup + screen-tile binning, near/guard-band clipper, and a tile rasteriser with
+// the pixel shader (terrain_ps.hlsl) fused into its resolve phase.
+//
+// Design (sort-middle, visibility-buffer in LDS):
+//   k_vertex : one lane per (instance, grid vertex); heightmap taps are byte loads
+//              served by L2/Infinity Cache; output 48 B/vertex (clip + snapped).
+//   k_setup  : one lane per triangle; cull (frustum, back-face, no-sample) and count
+//              the 64x64 raster tiles it touches (global atomics, ~1 per triangle).
+//              Triangles that cross the near plane / leave the guard band go to a
+//              small list for k_clip, which emits explicit sub-triangles.
+//   k_scan/k_fill : two-pass bin fill.  Order inside a bin is arbitrary — depth ties
+//              are resolved by a draw-order key, not by arrival order.
+//   k_raster : one workgroup per raster tile.  A 64x64 x u64 visibility buffer
+//              (32 KiB LDS) holds (depth bits << 32 | ~draw order) per pixel; LessOrEqual
+//              in-order depth testing == 64-bit ds_min.  Small triangles are rasterised by
+//              their own lane; big ones are broadcast with v_readlane and swept by all
+//              64 lanes of the wave in 8x8 pixel blocks.  The resolve phase shades each
+//              pixel's winner once (no overdraw shading) and leaves the tile with
+//              16-byte coalesced stores per plane (28 B/pixel).
+// Edge functions are exact (24.8 fixed point, 64-bit integers) with the D3D top-left
+// rule; all float math is in fixed order with contraction off, so the G-buffer is
+// bit-identical to the CPU oracle.
+#include "vr_internal.h"
+#include "vr_tex_dev.h"
+
+#include <string.h>
+
+struct VertexArgs {
+    float w2v[16], v2c[16];
+    float cam_x, cam_z;
+    float lod_ranges[VR_MAX_LODS];
+    float morph_start, world_size, max_height;
+    float vp_x, vp_y, vp_w, vp_h;
+};
+
+struct RasterArgs {
+    int w, h;                       // render target size
+    int vx0, vy0, vx1, vy1;         // inclusive pixel bounds (viewport ∩ target)
+    int rtx, rty;                   // raster tiles per row / column
+    int mirrored;
+    int world, rank;                // partition (world <= 1: whole frame)
+    int depth_only, assume_cleared;
+    float world_size;
+    uint32_t bin_capacity;
+    uint32_t extra_vert_base, extra_vert_cap, hard_cap;
+    float vp_x, vp_y, vp_w, vp_h;
+};
+
+// counters[]: 0 selected nodes, 1 status flags, 2 hard sub-triangles, 3 extra verts,
+//             4 hard-list length, 5 total bin entries
+enum { C_COUNT = 0, C_FLAGS = 1, C_HARDTRIS = 2, C_XVERTS = 3, C_HARDLIST = 4, C_BINTOTAL = 5 };
+
+
+// ---------------------------------------------------------------------------------------
+// vertex stage (terrain_vs.hlsl:35-62)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void snap_vertex(DevVert& v, float vp_x, float vp_y, float vp_w, float vp_h)
+{
+    float iw = 1.0f / v.cw;
+    float nx = v.cx * iw, ny = v.cy * iw;
+    float sx = (nx * 0.5f + 0.5f) * vp_w + vp_x;
+    float sy = (ny * -0.5f + 0.5f) * vp_h + vp_y;
+    float fx = floorf(sx * 256.0f + 0.5f), fy = floorf(sy * 256.0f + 0.5f);
+    // vertices outside the guard band are never rasterised from these values (k_setup
+    // sends their triangles to the clipper); clamp so the conversion is defined
+    fx = vr_min(vr_max(fx, -1.0e9f), 1.0e9f); fy = vr_min(vr_max(fy, -1.0e9f), 1.0e9f);
+    v.X = (int32_t)fx; v.Y = (int32_t)fy;
+    v.z = v.cz * iw; v.iw = iw;
+}
+
+__global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const vr_instance* __restrict__ inst,
+                                                 const uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
+{
+    const uint32_t total = counters[C_COUNT] * (uint32_t)kVertsPerInst;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        const uint32_t i = v / kVertsPerInst, r = v - i * kVertsPerInst;
+        const int vz = (int)(r / kSide), vx = (int)(r - (uint32_t)vz * kSide);
+        const float* M = inst[i].transform;
+        const float half = (float)(kGrid / 2), gs = (float)kGrid;
+        const float p0 = (float)(vx - kGrid / 2) / half, p1 = 0.0f, p2 = (float)(vz - kGrid / 2) / half;   // TerrainPass.cpp:63
+        float world[4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) world[k] = ((M[k * 4 + 0] * p0 + M[k * 4 + 1] * p1) + M[k * 4 + 2] * p2) + M[k * 4 + 3] * 1.0f;   // :44
+        world[3] = 1.0f;
+        const float dx = world[0] - a.cam_x, dz = world[2] - a.cam_z;
+        const float distance = sqrtf(dx * dx + dz * dz);                                            // :46
+        const float gridExtents = 2.0f * sqrtf((M[0] * M[0] + M[4] * M[4]) + M[8] * M[8]);          // :47
+        // computeMorphK (:16-25): int(log2(x)) == exponent for x >= 1, clamps to 0 below
+        int lod = gridExtents > 0.0f ? (int)((__float_as_uint(gridExtents) >> 23) & 255u) - 127 : 0;
+        lod = lod < 0 ? 0 : (lod > 11 ? 11 : lod);
+        const float start = a.lod_ranges[lod] * a.morph_start, end = a.lod_ranges[lod];
+        const float delta = end - start;
+        const float morphK = vr_saturate((distance - start) / delta);
+        // morphVertex (:10-14)
+        const float gp0 = (p0 + 1.0f) * 0.5f, gp1 = (p2 + 1.0f) * 0.5f;                               // :49
+        {
+            float q = gp0 * gs * 0.5f; float fr = (q - floorf(q)) * 2.0f / gs;
+            world[0] = world[0] - fr * gridExtents * morphK;
+            q = gp1 * gs * 0.5f; fr = (q - floorf(q)) * 2.0f / gs;
+            world[2] = world[2] - fr * gridExtents * morphK;
+        }
+        // sampleHeight (:27-33)
+        const float halfSize = a.world_size * 0.5f;
+        const float u = (world[0] + halfSize) / a.world_size, w_ = (world[2] + halfSize) / a.world_size;
+        world[1] = vr_trilinear_r8(hm, 0.1f, u, w_) * a.max_height;                                  // :51
+        float viewPos[4], clip[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) viewPos[j] = ((world[0] * a.w2v[0 * 4 + j] + world[1] * a.w2v[1 * 4 + j]) + world[2] * a.w2v[2 * 4 + j]) + world[3] * a.w2v[3 * 4 + j];   // :60
+#pragma unroll
+        for (int j = 0; j < 4; j++) clip[j] = ((viewPos[0] * a.v2c[0 * 4 + j] + viewPos[1] * a.v2c[1 * 4 + j]) + viewPos[2] * a.v2c[2 * 4 + j]) + viewPos[3] * a.v2c[3 * 4 + j];   // :61
+        DevVert o;
+        o.cx = clip[0]; o.cy = clip[1]; o.cz = clip[2]; o.cw = clip[3];
+        o.wx = world[0]; o.wz = world[2];
+        o.pad0 = 0; o.pad1 = 0;
+        if (o.cw > 0.0f) snap_vertex(o, a.vp_x, a.vp_y, a.vp_w, a.vp_h);
+        else { o.X = 0; o.Y = 0; o.z = 0.0f; o.iw = 0.0f; }
+        verts[v] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// triangle setup shared by binning and rasterisation
+// ---------------------------------------------------------------------------------------
+struct ScreenVert { int32_t X, Y; float z, iw; float wx, wz; };
+
+__device__ __forceinline__ ScreenVert load_sv(const DevVert* __restrict__ verts, uint32_t idx)
+{
+    const float4 b = *reinterpret_cast<const float4*>(&verts[idx].wx);   // wx, wz, X, Y
+    const float2 c = *reinterpret_cast<const float2*>(&verts[idx].z);    // z, iw
+    ScreenVert s;
+    s.wx = b.x; s.wz = b.y; s.X = __float_as_int(b.z); s.Y = __float_as_int(b.w); s.z = c.x; s.iw = c.y;
+    return s;
+}
+
+__device__ __forceinline__ void regular_tri_indices(uint32_t tri, uint32_t& i0, uint32_t& i1, uint32_t& i2)
+{
+    // index buffer (TerrainPass.cpp:68-87): per cell (BL,TL,TR), (BL,TR,BR); row = z, column = x
+    const uint32_t inst = tri >> 11, rem = tri & 2047u, cell = rem >> 1, second = rem & 1u;
+    const uint32_t ci = cell >> 5, cj = cell & 31u;
+    const uint32_t bl = inst * kVertsPerInst + ci * kSide + cj, tl = bl + kSide, tr = tl + 1, br = bl + 1;
+    i0 = bl; i1 = second ? tr : tl; i2 = second ? br : tr;
+}
+
+struct TriSetup {
+    int32_t A0, B0, A1, B1, A2, B2;   // E_i(PX,PY) = A_i*PX + B_i*PY + C_i
+    int64_t C0, C1, C2;
+    int32_t bias0, bias1, bias2;      // 0 for top-left edges, else 1
+    float z0, dz1, dz2, inv_area;
+    int x0, y0, x1, y1;               // inclusive pixel bounds after clamping
+    bool visible;
+};
+
+__device__ __forceinline__ bool is_top_left(int32_t dx, int32_t dy) { return (dy < 0) || (dy == 0 && dx > 0); }
+
+// Orders the vertices clockwise on the (y-down) target, applies the cull state of
+// TerrainPass::CreateGraphicsPipeline (TerrainPass.cpp:474-476), and returns edge
+// functions + the pixel bounding box clamped to [bx0..bx1] x [by0..by1].
+__device__ __forceinline__ TriSetup tri_setup(ScreenVert& s0, ScreenVert& s1, ScreenVert& s2, int mirrored,
+                                              int bx0, int by0, int bx1, int by1)
+{
+    TriSetup t;
+    t.visible = false;
+    int64_t area2 = (int64_t)(s1.X - s0.X) * (int64_t)(s2.Y - s0.Y) - (int64_t)(s2.X - s0.X) * (int64_t)(s1.Y - s0.Y);
+    if (area2 == 0) return t;
+    const bool cw = area2 > 0;
+    const bool front = mirrored ? !cw : cw;
+    if (!front) return t;
+    if (!cw) { ScreenVert tmp = s1; s1 = s2; s2 = tmp; area2 = -area2; }
+    const int32_t minX = min(s0.X, min(s1.X, s2.X)), maxX = max(s0.X, max(s1.X, s2.X));
+    const int32_t minY = min(s0.Y, min(s1.Y, s2.Y)), maxY = max(s0.Y, max(s1.Y, s2.Y));
+    t.x0 = max((minX - 128 + 255) >> 8, bx0); t.x1 = min((maxX - 128) >> 8, bx1);
+    t.y0 = max((minY - 128 + 255) >> 8, by0); t.y1 = min((maxY - 128) >> 8, by1);
+    if (t.x0 > t.x1 || t.y0 > t.y1) return t;
+    // edge(a,b)(p) = (bX-aX)*(py-aY) - (bY-aY)*(px-aX)
+    t.B0 = s2.X - s1.X; t.A0 = -(s2.Y - s1.Y); t.C0 = -(int64_t)t.B0 * s1.Y - (int64_t)t.A0 * s1.X;
+    t.B1 = s0.X - s2.X; t.A1 = -(s0.Y - s2.Y); t.C1 = -(int64_t)t.B1 * s2.Y - (int64_t)t.A1 * s2.X;
+    t.B2 = s1.X - s0.X; t.A2 = -(s1.Y - s0.Y); t.C2 = -(int64_t)t.B2 * s0.Y - (int64_t)t.A2 * s0.X;
+    t.bias0 = is_top_left(s2.X - s1.X, s2.Y - s1.Y) ? 0 : 1;
+    t.bias1 = is_top_left(s0.X - s2.X, s0.Y - s2.Y) ? 0 : 1;
+    t.bias2 = is_top_left(s1.X - s0.X, s1.Y - s0.Y) ? 0 : 1;
+    t.inv_area = 1.0f / (float)area2;
+    t.z0 = s0.z; t.dz1 = s1.z - s0.z; t.dz2 = s2.z - s0.z;
+    t.visible = true;
+    return t;
+}
+
+__device__ __forceinline__ bool tile_owned(const RasterArgs& a, int tx, int ty)
+{
+    if (a.world <= 1) return true;
+    const int sub = VR_OWNER_TILE / kRasterTile;
+    return ((tx / sub + ty / sub) % a.world) == a.rank;
+}
+
+__device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1)
+{
+    return (uint64_t)(uint32_t)tx0 | ((uint64_t)(uint32_t)ty0 << 16) | ((uint64_t)(uint32_t)tx1 << 32) | ((uint64_t)(uint32_t)ty1 << 48);
+}
+
+__device__ __forceinline__ uint64_t bin_count_triangle(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2,
+                                                        uint32_t* __restrict__ tile_count)
+{
+    TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+    if (!t.visible) return ~0ull;
+    const int tx0 = t.x0 / kRasterTile, tx1 = t.x1 / kRasterTile, ty0 = t.y0 / kRasterTile, ty1 = t.y1 / kRasterTile;
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++)
+            if (tile_owned(a, tx, ty)) atomicAdd(&tile_count[ty * a.rtx + tx], 1u);
+    return pack_rect(tx0, ty0, tx1, ty1);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_setup: regular triangles
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
+                                                uint64_t* __restrict__ rect, uint32_t* __restrict__ hard_list,
+                                                uint32_t* __restrict__ tile_count)
+{
+    const uint32_t total = counters[C_COUNT] * (uint32_t)kTrisPerInst;
+    for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < total; tri += gridDim.x * blockDim.x) {
+        uint32_t i0, i1, i2;
+        regular_tri_indices(tri, i0, i1, i2);
+        const float4 c0 = *reinterpret_cast<const float4*>(&verts[i0].cx);
+        const float4 c1 = *reinterpret_cast<const float4*>(&verts[i1].cx);
+        const float4 c2 = *reinterpret_cast<const float4*>(&verts[i2].cx);
+        // trivial reject against the six clip planes
+        const bool out_l = (c0.x < -c0.w) && (c1.x < -c1.w) && (c2.x < -c2.w);
+        const bool out_r = (c0.x > c0.w) && (c1.x > c1.w) && (c2.x > c2.w);
+        const bool out_b = (c0.y < -c0.w) && (c1.y < -c1.w) && (c2.y < -c2.w);
+        const bool out_t = (c0.y > c0.w) && (c1.y > c1.w) && (c2.y > c2.w);
+        const bool out_n = (c0.z < 0.0f) && (c1.z < 0.0f) && (c2.z < 0.0f);
+        const bool out_f = (c0.z > c0.w) && (c1.z > c1.w) && (c2.z > c2.w);
+        uint64_t r = ~0ull;
+        if (!(out_l || out_r || out_b || out_t || out_n || out_f)) {
+            const bool need_near = (c0.z < 0.0f) || (c1.z < 0.0f) || (c2.z < 0.0f);
+            const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+            const bool need_guard = (c0.x < -g0) || (c0.x > g0) || (c0.y < -g0) || (c0.y > g0)
+                                 || (c1.x < -g1) || (c1.x > g1) || (c1.y < -g1) || (c1.y > g1)
+                                 || (c2.x < -g2) || (c2.x > g2) || (c2.y < -g2) || (c2.y > g2);
+            if (need_near || need_guard) {
+                const uint32_t slot = atomicAdd(&counters[C_HARDLIST], 1u);
+                if (slot < a.hard_cap) hard_list[slot] = tri; else atomicOr(&counters[C_FLAGS], 2u);
+            } else {
+                r = bin_count_triangle(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), tile_count);
+            }
+        }
+        rect[tri] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_clip: triangles crossing z = 0 or leaving the guard band (rare)
+// ---------------------------------------------------------------------------------------
+struct ClipVert { float c[4]; float wx, wz; };
+
+__device__ int clip_poly(ClipVert* poly, int n, int plane)
+{
+    ClipVert out[12];
+    float d[12];
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const float* c = poly[i].c;
+        switch (plane) {
+        case 0: d[i] = c[2]; break;
+        case 1: d[i] = kGuardBand * c[3] + c[0]; break;
+        case 2: d[i] = kGuardBand * c[3] - c[0]; break;
+        case 3: d[i] = kGuardBand * c[3] + c[1]; break;
+        default: d[i] = kGuardBand * c[3] - c[1]; break;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        const bool ini = d[i] >= 0.0f, inj = d[j] >= 0.0f;
+        if (ini) out[m++] = poly[i];
+        if (ini != inj) {
+            // always interpolate from the inside vertex towards the outside vertex so both
+            // triangles that share the edge create the identical vertex
+            const ClipVert& va = ini ? poly[i] : poly[j];
+            const ClipVert& vb = ini ? poly[j] : poly[i];
+            const float da = ini ? d[i] : d[j], db = ini ? d[j] : d[i];
+            const float tt = da / (da - db);
+            ClipVert nv;
+            for (int k = 0; k < 4; k++) nv.c[k] = va.c[k] + (vb.c[k] - va.c[k]) * tt;
+            nv.wx = va.wx + (vb.wx - va.wx) * tt;
+            nv.wz = va.wz + (vb.wz - va.wz) * tt;
+            out[m++] = nv;
+        }
+    }
+    for (int i = 0; i < m; i++) poly[i] = out[i];
+    return m;
+}
+
+__global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
+                                              const uint32_t* __restrict__ hard_list, HardTriRec* __restrict__ hard_tris,
+                                              uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count)
+{
+    const uint32_t n_hard = min(counters[C_HARDLIST], a.hard_cap);
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_hard; h += gridDim.x * blockDim.x) {
+        const uint32_t tri = hard_list[h];
+        uint32_t idx[3];
+        regular_tri_indices(tri, idx[0], idx[1], idx[2]);
+        ClipVert poly[12];
+        bool need_near = false;
+        for (int k = 0; k < 3; k++) {
+            const DevVert& v = verts[idx[k]];
+            poly[k].c[0] = v.cx; poly[k].c[1] = v.cy; poly[k].c[2] = v.cz; poly[k].c[3] = v.cw;
+            poly[k].wx = v.wx; poly[k].wz = v.wz;
+            need_near |= v.cz < 0.0f;
+        }
+        int n = 3;
+        if (need_near) n = clip_poly(poly, n, 0);
+        if (n >= 3) {
+            bool need_guard = false;
+            for (int i = 0; i < n; i++) {
+                const float g = kGuardBand * poly[i].c[3];
+                need_guard |= (poly[i].c[0] < -g) || (poly[i].c[0] > g) || (poly[i].c[1] < -g) || (poly[i].c[1] > g);
+            }
+            if (need_guard) for (int pl = 1; pl <= 4 && n >= 3; pl++) n = clip_poly(poly, n, pl);
+        }
+        if (n < 3) { hard_first[tri] = 0xffffffffu; continue; }
+        const uint32_t nsub = (uint32_t)(n - 2);
+        const uint32_t vbase = atomicAdd(&counters[C_XVERTS], (uint32_t)n);
+        const uint32_t tbase = atomicAdd(&counters[C_HARDTRIS], nsub);
+        if (vbase + (uint32_t)n > a.extra_vert_cap || tbase + nsub > a.hard_cap * 4u) {
+            atomicOr(&counters[C_FLAGS], 2u); hard_first[tri] = 0xffffffffu; continue;
+        }
+        for (int i = 0; i < n; i++) {
+            DevVert o;
+            o.cx = poly[i].c[0]; o.cy = poly[i].c[1]; o.cz = poly[i].c[2]; o.cw = poly[i].c[3];
+            o.wx = poly[i].wx; o.wz = poly[i].wz; o.pad0 = 0; o.pad1 = 0;
+            snap_vertex(o, a.vp_x, a.vp_y, a.vp_w, a.vp_h);
+            verts[a.extra_vert_base + vbase + (uint32_t)i] = o;
+        }
+        hard_first[tri] = tbase;
+        for (uint32_t s = 0; s < nsub; s++) {
+            HardTriRec rec;
+            rec.v0 = a.extra_vert_base + vbase; rec.v1 = rec.v0 + s + 1; rec.v2 = rec.v0 + s + 2;
+            rec.order_key = (tri << 4) | (s << 1) | 1u;
+            const uint64_t r = bin_count_triangle(a, load_sv(verts, rec.v0), load_sv(verts, rec.v1), load_sv(verts, rec.v2), tile_count);
+            rec.rect_lo = (uint32_t)r; rec.rect_hi = (uint32_t)(r >> 32); rec.pad0 = 0; rec.pad1 = 0;
+            hard_tris[tbase + s] = rec;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_scan: exclusive prefix sum of the per-tile counts (one workgroup)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(int n_tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity)
+{
+    __shared__ uint32_t partial[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_tiles + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, n_tiles);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += tile_count[i];
+    partial[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? partial[tid - off] : 0u;
+        __syncthreads();
+        partial[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[tid] - s;
+    for (int i = b; i < e; i++) { tile_offset[i] = run; tile_cursor[i] = run; run += tile_count[i]; }
+    if (tid == 1023) {
+        counters[C_BINTOTAL] = partial[1023];
+        if (partial[1023] > capacity) atomicOr(&counters[C_FLAGS], 2u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_fill: write bin entries.  Entry = draw-order key: (triangle id << 4) | (sub << 1) | hard.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void fill_rect(const RasterArgs& a, uint64_t r, uint32_t entry, uint32_t* __restrict__ tile_cursor,
+                                          uint32_t* __restrict__ entries)
+{
+    const int tx0 = (int)(r & 0xffffu), ty0 = (int)((r >> 16) & 0xffffu), tx1 = (int)((r >> 32) & 0xffffu), ty1 = (int)((r >> 48) & 0xffffu);
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++)
+            if (tile_owned(a, tx, ty)) {
+                const uint32_t pos = atomicAdd(&tile_cursor[ty * a.rtx + tx], 1u);
+                if (pos < a.bin_capacity) entries[pos] = entry;
+            }
+}
+
+__global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __restrict__ counters, const uint64_t* __restrict__ rect,
+                                               const HardTriRec* __restrict__ hard_tris, uint32_t* __restrict__ tile_cursor,
+                                               uint32_t* __restrict__ entries)
+{
+    const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
+    const uint32_t n_hard = min(counters[C_HARDTRIS], a.hard_cap * 4u);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reg + n_hard; i += gridDim.x * blockDim.x) {
+        if (i < n_reg) {
+            const uint64_t r = rect[i];
+            if (r != ~0ull) fill_rect(a, r, i << 4, tile_cursor, entries);
+        } else {
+            const HardTriRec rec = hard_tris[i - n_reg];
+            const uint64_t r = (uint64_t)rec.rect_lo | ((uint64_t)rec.rect_hi << 32);
+            if (r != ~0ull) fill_rect(a, r, rec.order_key, tile_cursor, entries);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_raster: one workgroup per 64x64 raster tile
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void entry_vertices(uint32_t key, const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
+                                               uint32_t& i0, uint32_t& i1, uint32_t& i2)
+{
+    const uint32_t tri = key >> 4;
+    if (key & 1u) {
+        const HardTriRec rec = hard_tris[hard_first[tri] + ((key >> 1) & 7u)];
+        i0 = rec.v0; i1 = rec.v1; i2 = rec.v2;
+    } else {
+        regular_tri_indices(tri, i0, i1, i2);
+    }
+}
+
+__device__ __forceinline__ int64_t edge_eval(int32_t A, int32_t B, int64_t C, int32_t PX, int32_t PY)
+{
+    return (int64_t)A * PX + ((int64_t)B * PY + C);
+}
+
+struct Attr { float wx, wz; };
+__device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, float inv_area, int64_t E1, int64_t E2)
+{
+    const float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
+    const float l0 = (1.0f - l1) - l2;
+    const float q0 = l0 * v0.iw, q1 = l1 * v1.iw, q2 = l2 * v2.iw;
+    const float den = (q0 + q1) + q2;
+    const float r = 1.0f / den;
+    const float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
+    Attr o;
+    o.wx = (b0 * v0.wx + b1 * v1.wx) + b2 * v2.wx;
+    o.wz = (b0 * v0.wz + b1 * v1.wz) + b2 * v2.wz;
+    return o;
+}
+
+// main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels
+__device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
+                                             const float* __restrict__ thr, Attr p, Attr pr, Attr pd,
+                                             uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
+{
+    const float halfSize = a.world_size * 0.5f, ws = a.world_size;
+    const float u = (p.wx + halfSize) / ws, v = (p.wz + halfSize) / ws;                     // :12-13, :20-21
+    const float ux = (pr.wx + halfSize) / ws, vx = (pr.wz + halfSize) / ws;
+    const float uy = (pd.wx + halfSize) / ws, vy = (pd.wz + halfSize) / ws;
+    const float dudx = ux - u, dvdx = vx - v, dudy = uy - u, dvdy = vy - v;
+    const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
+    const float lod_c = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
+    const float offset = 0.1f;                                                              // :59
+    const float hDx = vr_trilinear_r8(hm, lod_h, u + offset, v + 0.0f) - vr_trilinear_r8(hm, lod_h, u + (-offset), v + 0.0f);   // :60
+    const float hDy = vr_trilinear_r8(hm, lod_h, u + 0.0f, v + offset) - vr_trilinear_r8(hm, lod_h, u + 0.0f, v + (-offset));   // :61
+    float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
+    const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
+    nx *= inv; ny *= inv; nz *= inv;
+    float col[3];
+    vr_trilinear_srgb(al, lod_c, u, v, lut, col);                                           // :68
+    diffuse = vr_srgb_encode(col[0], thr) | (vr_srgb_encode(col[1], thr) << 8) | (vr_srgb_encode(col[2], thr) << 16) | 0xff000000u;   // :73-75
+    n01 = vr_snorm16(nx) | (vr_snorm16(ny) << 16);                                          // :78
+    n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
+}
+
+constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
+
+__global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
+                                                 const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
+                                                 const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
+                                                 const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
+                                                 float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
+                                                 uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
+                                                 const float* __restrict__ lut_g, const float* __restrict__ thr_g, uint32_t spec_const)
+{
+    __shared__ unsigned long long vis[kRasterTile * kRasterTile];
+    __shared__ float lut[256];
+    __shared__ float thr[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
+    const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
+    const int ox = txi * kRasterTile, oy = tyi * kRasterTile;
+    lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid];
+    // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
+    for (int i = tid; i < kRasterTile * kRasterTile; i += 256) {
+        const int lx = i & (kRasterTile - 1), ly = i >> 6;
+        const int gx = ox + lx, gy = oy + ly;
+        unsigned long long key = 0ull;                         // outside the target: nothing passes
+        if (gx < a.w && gy < a.h) {
+            const uint32_t dbits = a.assume_cleared ? 0x3f800000u : __float_as_uint(g_depth[(size_t)gy * a.w + gx]);
+            key = ((unsigned long long)dbits << 32) | 0xffffffffull;
+        }
+        vis[i] = key;
+    }
+    __syncthreads();
+
+    const uint32_t n = tile_count[tile], off = tile_offset[tile];
+    const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + kRasterTile - 1, a.vx1), by1 = min(oy + kRasterTile - 1, a.vy1);
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t idx = base + (uint32_t)tid;
+        bool valid = idx < n && (off + idx) < a.bin_capacity;
+        uint32_t key = 0;
+        TriSetup t; t.visible = false;
+        if (valid) {
+            key = entries[off + idx];
+            uint32_t i0, i1, i2;
+            entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
+            ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
+            t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1);
+        }
+        valid = valid && t.visible;
+        const uint32_t order = ~key;
+        const int bw = valid ? t.x1 - t.x0 + 1 : 0, bh = valid ? t.y1 - t.y0 + 1 : 0;
+        const bool small = valid && (bw * bh <= kSmallArea);
+        if (small) {
+            for (int y = t.y0; y <= t.y1; y++) {
+                const int32_t PY = y * 256 + 128;
+                for (int x = t.x0; x <= t.x1; x++) {
+                    const int32_t PX = x * 256 + 128;
+                    const int64_t E0 = edge_eval(t.A0, t.B0, t.C0, PX, PY), E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
+                    if (E0 - t.bias0 < 0 || E1 - t.bias1 < 0 || E2 - t.bias2 < 0) continue;
+                    const float l1 = (float)E1 * t.inv_area, l2 = (float)E2 * t.inv_area;
+                    float z = (t.z0 + l1 * t.dz1) + l2 * t.dz2;
+                    if (!(z >= 0.0f && z <= 1.0f)) continue;
+                    z = z + 0.0f;                                   // canonical +0
+                    atomicMin(&vis[(y - oy) * kRasterTile + (x - ox)], ((unsigned long long)__float_as_uint(z) << 32) | order);
+                }
+            }
+        }
+        // big triangles: broadcast one at a time, all 64 lanes sweep its bbox in 8x8 blocks
+        unsigned long long big = __ballot(valid && !small);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+#define BC(v) __builtin_amdgcn_readlane((int)(v), src)
+            const int32_t A0 = BC(t.A0), B0 = BC(t.B0), A1 = BC(t.A1), B1 = BC(t.B1), A2 = BC(t.A2), B2 = BC(t.B2);
+            const int64_t C0 = ((int64_t)BC((int32_t)(t.C0 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C0);
+            const int64_t C1 = ((int64_t)BC((int32_t)(t.C1 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C1);
+            const int64_t C2 = ((int64_t)BC((int32_t)(t.C2 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C2);
+            const int32_t bb0 = BC(t.bias0), bb1 = BC(t.bias1), bb2 = BC(t.bias2);
+            const float z0 = __int_as_float(BC(__float_as_int(t.z0))), dz1 = __int_as_float(BC(__float_as_int(t.dz1)));
+            const float dz2 = __int_as_float(BC(__float_as_int(t.dz2))), ia = __int_as_float(BC(__float_as_int(t.inv_area)));
+            const int x0 = BC(t.x0), y0 = BC(t.y0), x1 = BC(t.x1), y1 = BC(t.y1);
+            const uint32_t ord = (uint32_t)BC((int32_t)order);
+#undef BC
+            const int lx = lane & 7, ly = lane >> 3;
+            for (int yb = y0 & ~7; yb <= y1; yb += 8) {
+                for (int xb = x0 & ~7; xb <= x1; xb += 8) {
+                    const int x = xb + lx, y = yb + ly;
+                    if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+                    const int32_t PX = x * 256 + 128, PY = y * 256 + 128;
+                    const int64_t E0 = edge_eval(A0, B0, C0, PX, PY), E1 = edge_eval(A1, B1, C1, PX, PY), E2 = edge_eval(A2, B2, C2, PX, PY);
+                    if (E0 - bb0 < 0 || E1 - bb1 < 0 || E2 - bb2 < 0) continue;
+                    const float l1 = (float)E1 * ia, l2 = (float)E2 * ia;
+                    float z = (z0 + l1 * dz1) + l2 * dz2;
+                    if (!(z >= 0.0f && z <= 1.0f)) continue;
+                    z = z + 0.0f;
+                    atomicMin(&vis[(y - oy) * kRasterTile + (x - ox)], ((unsigned long long)__float_as_uint(z) << 32) | ord);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
+    const bool vec_ok = (a.w & 3) == 0;
+    for (int g = tid; g < kRasterTile * kRasterTile / 4; g += 256) {
+        const int ly = g >> 4, lx0 = (g & 15) * 4;
+        const int gy = oy + ly, gx0 = ox + lx0;
+        if (gy >= a.h || gx0 >= a.w) continue;
+        uint32_t covered = 0;
+        float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long key = vis[ly * kRasterTile + lx0 + k];
+            const uint32_t low = (uint32_t)key;
+            dep[k] = __uint_as_float((uint32_t)(key >> 32)); dif[k] = 0; nn0[k] = 0; nn1[k] = 0;
+            if (low == 0xffffffffu || gx0 + k >= a.w) continue;
+            covered |= 1u << k;
+            if (a.depth_only) continue;
+            uint32_t i0, i1, i2;
+            entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
+            ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
+            TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+            const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
+            const Attr p = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX, PY), edge_eval(t.A2, t.B2, t.C2, PX, PY));
+            const Attr pr = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX + 256, PY), edge_eval(t.A2, t.B2, t.C2, PX + 256, PY));
+            const Attr pd = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX, PY + 256), edge_eval(t.A2, t.B2, t.C2, PX, PY + 256));
+            pixel_shader(a, hm, al, lut, thr, p, pr, pd, dif[k], nn0[k], nn1[k]);
+        }
+        const size_t pix = (size_t)gy * a.w + gx0;
+        const int npx = min(4, a.w - gx0);
+        const uint32_t all = (1u << npx) - 1u;
+        if (!a.assume_cleared && covered == 0) continue;          // nothing of this group was drawn
+        if (vec_ok && (covered == all || a.assume_cleared)) {
+            // every pixel of the group is defined: drawn, or the clear value
+            *reinterpret_cast<float4*>(g_depth + pix) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+            if (!a.depth_only) {
+                uint32_t sp[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) sp[k] = (covered >> k) & 1u ? spec_const : 0u;
+                *reinterpret_cast<uint4*>(g_diff + pix) = make_uint4(dif[0], dif[1], dif[2], dif[3]);
+                *reinterpret_cast<uint4*>(g_spec + pix) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+                *reinterpret_cast<uint4*>(g_nrm + pix) = make_uint4(nn0[0], nn1[0], nn0[1], nn1[1]);
+                *reinterpret_cast<uint4*>(g_nrm + pix + 2) = make_uint4(nn0[2], nn1[2], nn0[3], nn1[3]);
+                *reinterpret_cast<uint4*>(g_emi + pix) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(g_emi + pix + 2) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
+            for (int k = 0; k < npx; k++) {
+                const bool c = (covered >> k) & 1u;
+                if (!c && !a.assume_cleared) continue;            // keep what the target holds
+                g_depth[pix + k] = dep[k];
+                if (!a.depth_only) {
+                    g_diff[pix + k] = dif[k];
+                    g_spec[pix + k] = c ? spec_const : 0u;
+                    g_nrm[pix + k] = make_uint2(nn0[k], nn1[k]);
+                    g_emi[pix + k] = make_uint2(0u, 0u);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host: TerrainPass::Render (TerrainPass.cpp:143-232)
+// ---------------------------------------------------------------------------------------
+static uint32_t host_srgb_encode(const vr_context* c, float x)
+{
+    if (!(x >= 0.0f)) return 0;
+    int lo = 0, hi = 255;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
+    return (uint32_t)lo;
+}
+
+extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev, vr_gbuffer* gb,
+                                         const vr_render_params* rp, const vr_partition* part)
+{
+    (void)view_prev;   // MOTION_VECTORS = 0 (TerrainPass.cpp:361,368)
+    VR_REQUIRE(t && view && gb && rp, "NULL argument");
+    VR_REQUIRE(!rp->wireframe, "wireframe fill mode is not implemented");
+    VR_REQUIRE(!view->reverse_depth, "reverse depth is not supported (the reference disables it, Renderer.cpp:221)");
+    VR_REQUIRE(view->viewport_w > 0 && view->viewport_h > 0 && view->viewport_w <= 16384 && view->viewport_h <= 16384, "bad viewport");
+    VR_REQUIRE(gb->ctx == t->ctx, "G-buffer and terrain belong to different contexts");
+    vr_context* ctx = t->ctx;
+    VR_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc;
+    if (!rp->lock_view || !t->have_selection) {                       // TerrainPass.cpp:173-190
+        if ((rc = vr_select_launch(t, view, rp->max_height))) return rc;
+    }
+    const int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
+    VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
+    if ((rc = vr_ensure_partition(ctx, gb->w, gb->h, part))) return rc;
+
+    RasterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = gb->w; a.h = gb->h;
+    a.vx0 = view->viewport_x; a.vy0 = view->viewport_y;
+    a.vx1 = view->viewport_x + view->viewport_w - 1; a.vy1 = view->viewport_y + view->viewport_h - 1;
+    if (a.vx0 < 0) a.vx0 = 0;
+    if (a.vy0 < 0) a.vy0 = 0;
+    if (a.vx1 > gb->w - 1) a.vx1 = gb->w - 1;
+    if (a.vy1 > gb->h - 1) a.vy1 = gb->h - 1;
+    a.rtx = (gb->w + kRasterTile - 1) / kRasterTile; a.rty = (gb->h + kRasterTile - 1) / kRasterTile;
+    a.mirrored = view->mirrored; a.world = world; a.rank = rank;
+    a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared;
+    a.world_size = t->p.world_size;
+    a.bin_capacity = (uint32_t)t->bin_capacity;
+    a.extra_vert_base = (uint32_t)t->p.max_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
+    a.vp_x = (float)view->viewport_x; a.vp_y = (float)view->viewport_y; a.vp_w = (float)view->viewport_w; a.vp_h = (float)view->viewport_h;
+
+    const int n_tiles = a.rtx * a.rty;
+    if (n_tiles > t->scratch_tiles) {
+        VR_HIP(hipStreamSynchronize(s));
+        (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_offset); (void)hipFree(t->d_tile_cursor);
+        t->d_tile_count = t->d_tile_offset = t->d_tile_cursor = nullptr; t->scratch_tiles = 0;
+        VR_HIP(hipMalloc(&t->d_tile_count, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMalloc(&t->d_tile_offset, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMalloc(&t->d_tile_cursor, sizeof(uint32_t) * n_tiles));
+        t->scratch_tiles = n_tiles;
+    }
+    VR_HIP(hipMemsetAsync(t->d_tile_count, 0, sizeof(uint32_t) * n_tiles, s));
+    VR_HIP(hipMemsetAsync(t->d_counters + 2, 0, sizeof(uint32_t) * 6, s));
+
+    VertexArgs va;
+    for (int i = 0; i < 16; i++) { va.w2v[i] = view->world_to_view[i]; va.v2c[i] = view->view_to_clip[i]; }
+    va.cam_x = view->camera_pos[0]; va.cam_z = view->camera_pos[2];
+    for (int i = 0; i < VR_MAX_LODS; i++) va.lod_ranges[i] = t->lod_ranges[i];
+    va.morph_start = t->p.morph_start; va.world_size = t->p.world_size; va.max_height = rp->max_height;
+    va.vp_x = a.vp_x; va.vp_y = a.vp_y; va.vp_w = a.vp_w; va.vp_h = a.vp_h;
+
+    HardTriRec* hard_tris = t->d_hard_tris;
+    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, s, va, t->height, t->d_instances, t->d_counters, t->d_verts);
+    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, s, a, t->d_verts, t->d_counters, t->d_rect, t->d_hard_list, t->d_tile_count);
+    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, s, a, t->d_verts, t->d_counters, t->d_hard_list, hard_tris, t->d_hard_first, t->d_tile_count);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, n_tiles, t->d_tile_count, t->d_tile_offset, t->d_tile_cursor, t->d_counters, a.bin_capacity);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, a, t->d_counters, t->d_rect, hard_tris, t->d_tile_cursor, t->d_bin_entries);
+    const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
+    const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
+    const bool whole = world <= 1;
+    const int grid = whole ? n_tiles : ctx->num_raster_tiles;
+    if (grid > 0)
+        hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, t->d_verts, hard_tris, t->d_hard_first,
+                           t->d_tile_count, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, spec_const);
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}

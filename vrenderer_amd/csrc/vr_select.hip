@@ -1,0 +1,294 @@
+// Terrain object + quadtree LOD select on the device.
+//
+// The reference builds a pointer quadtree of (4^(L+1)-1)/3 heap nodes at start-up
+// (QuadTree::Split, QuadTree.cpp:210-232; 5.6 M nodes / 313 MB at L=11) and walks it
+// recursively every frame (QuadTree::NodeSelect, QuadTree.cpp:80-131).  Here the tree
+// is implicit: a node is its path from the root (2 bits per level, child order
+// TL,TR,BL,BR as QuadTree.h:51-54), its position/extents are recomputed by replaying
+// the same float additions Split performs, and selection is a level-synchronous sweep
+// in one workgroup: a frontier of paths in LDS, one lane per node, survivors expanded
+// into the next frontier.  The reference's m_SelectedNodes order (depth-first push
+// order) is the lexicographic order of left-aligned paths, recovered by a rank sort.
+// Nothing is allocated per frame and nothing crosses PCIe: UpdateTransforms
+// (TerrainPass.cpp:234-256) is fused into the write-out.
+#include "vr_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+constexpr int kSelThreads = 1024;
+constexpr int kFrontierCap = 4096;
+constexpr int kSelectedCap = 4096;   // LDS capacity == the largest max_instances (more is an error anyway)
+
+struct SelectArgs {
+    float cam[3];
+    float planes[6][4];
+    float range2[VR_MAX_LODS];   // m_LodRanges[i]^2
+    float loc[3];
+    float half_w, half_h;        // root extents (m_Width/2, m_Height/2)
+    int num_lods;
+    int max_instances;
+    int height_loaded;           // m_HeightLoaded (always 0 until row f2)
+    float max_height;
+};
+
+struct NodeGeom { float px, pz, ex, ez; uint32_t ix, iz; };
+
+// Replays QuadTree::Split's arithmetic along a path (QuadTree.cpp:212-216).
+__device__ __forceinline__ NodeGeom node_from_path(const SelectArgs& a, uint32_t path, int depth)
+{
+    NodeGeom g; g.px = a.loc[0]; g.pz = a.loc[2]; g.ex = a.half_w; g.ez = a.half_h; g.ix = 0; g.iz = 0;
+    for (int d = depth - 1; d >= 0; d--) {
+        uint32_t c = (path >> (2 * d)) & 3u;
+        g.ex = g.ex / 2.0f; g.ez = g.ez / 2.0f;
+        bool right = (c & 1u) != 0u, top = c < 2u;      // TL=0 TR=1 BL=2 BR=3
+        g.px = right ? g.px + g.ex : g.px - g.ex;
+        g.pz = top ? g.pz + g.ez : g.pz - g.ez;
+        g.ix = g.ix * 2u + (right ? 1u : 0u);
+        g.iz = g.iz * 2u + (top ? 1u : 0u);
+    }
+    return g;
+}
+
+// Node::Intersects (QuadTree.h:31-45): xz distance to the box vs a SQUARED range.
+__device__ __forceinline__ bool node_in_range(const NodeGeom& g, const float cam[3], float r2)
+{
+    float minx = g.px - g.ex, maxx = g.px + g.ex, minz = g.pz - g.ez, maxz = g.pz + g.ez;
+    float dx = 0.0f, dz = 0.0f;
+    if (cam[0] < minx) dx = cam[0] - minx; else if (cam[0] > maxx) dx = cam[0] - maxx;
+    if (cam[2] < minz) dz = cam[2] - minz; else if (cam[2] > maxz) dz = cam[2] - maxz;
+    return ((dx * dx + 0.0f) + dz * dz) <= r2;
+}
+
+// dm::frustum::intersectsWith(box3) (call site QuadTree.cpp:97-99).
+__device__ __forceinline__ bool box_in_frustum(const SelectArgs& a, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float nx = a.planes[i][0], ny = a.planes[i][1], nz = a.planes[i][2];
+        float x = nx > 0.0f ? mnx : mxx, y = ny > 0.0f ? mny : mxy, z = nz > 0.0f ? mnz : mxz;
+        float dist = ((nx * x + ny * y) + nz * z) - a.planes[i][3];
+        if (dist > 0.0f) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* __restrict__ node_ids,
+                                                        vr_instance* __restrict__ inst, uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t frontier[2][kFrontierCap];
+    __shared__ uint32_t selected[kSelectedCap];
+    __shared__ uint32_t n_front[2], n_sel, overflow;
+    const int tid = threadIdx.x;
+    const int L = a.num_lods;
+    if (tid == 0) { frontier[0][0] = 0u; n_front[0] = 1u; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
+    __syncthreads();
+
+    int cur = 0;
+    for (int lod = L; lod >= 0; lod--) {
+        const int depth = L - lod;
+        const uint32_t n = n_front[cur];
+        for (uint32_t i = tid; i < n; i += kSelThreads) {
+            uint32_t path = frontier[cur][i];
+            NodeGeom g = node_from_path(a, path, depth);
+            bool select_self = false, expand = false;
+            if (!node_in_range(g, a.cam, a.range2[lod])) {
+                // NodeSelect returned false: the parent pushes this child (QuadTree.cpp:120-126);
+                // the root's return value is ignored (TerrainPass.cpp:181).
+                select_self = depth > 0;
+            } else {
+                float mny = 0.0f, mxy = a.cam[1];                 // m_HeightLoaded == false (QuadTree.cpp:92-96)
+                if (box_in_frustum(a, g.px - g.ex, mny, g.pz - g.ez, g.px + g.ex, mxy, g.pz + g.ez)) {
+                    if (lod == 0) select_self = true;                                   // :106-111
+                    else if (!node_in_range(g, a.cam, a.range2[lod - 1])) select_self = true;   // :114-118
+                    else expand = true;                                                 // :119-128
+                }
+            }
+            if (select_self) {
+                uint32_t slot = atomicAdd(&n_sel, 1u);
+                if (slot < (uint32_t)kSelectedCap) selected[slot] = ((path << (2 * (L - depth))) << 4) | (uint32_t)depth;
+                else overflow = 1u;
+            }
+            if (expand) {
+                uint32_t slot = atomicAdd(&n_front[cur ^ 1], 4u);
+                if (slot + 4u <= (uint32_t)kFrontierCap) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4u; c++) frontier[cur ^ 1][slot + c] = (path << 2) | c;
+                } else overflow = 1u;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { n_front[cur] = 0u; if (n_front[cur ^ 1] > (uint32_t)kFrontierCap) n_front[cur ^ 1] = 0u; }
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // Depth-first order = ascending left-aligned path.  Keys are unique, so a node's
+    // rank is the number of smaller keys (LDS broadcast reads, no barriers).
+    uint32_t total = n_sel;
+    if (total > (uint32_t)kSelectedCap) total = kSelectedCap;
+    const uint32_t limit = min(total, (uint32_t)a.max_instances);
+    for (uint32_t i = tid; i < total; i += kSelThreads) {
+        uint32_t key = selected[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < total; j++) rank += selected[j] < key ? 1u : 0u;
+        if (rank >= limit) continue;
+        int depth = (int)(key & 15u);
+        uint32_t path = (key >> 4) >> (2 * (L - depth));
+        NodeGeom g = node_from_path(a, path, depth);
+        uint32_t base = (uint32_t)((((uint64_t)1 << (2 * depth)) - 1) / 3);
+        node_ids[rank] = base + g.iz * (1u << depth) + g.ix;
+        // scaling(extents) * translation(position) -> float3x4 rows (TerrainPass.cpp:245-253)
+        vr_instance o;
+        o.padding = 0u; o.first_geometry_instance_index = 0u; o.first_geometry_index = 0u; o.num_geometries = 1u;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { o.transform[k] = 0.0f; o.prev_transform[k] = 0.0f; }
+        o.transform[0] = g.ex; o.transform[3] = g.px;
+        o.transform[5] = 0.0f; o.transform[7] = a.loc[1];
+        o.transform[10] = g.ez; o.transform[11] = g.pz;
+        inst[rank] = o;
+    }
+    if (tid == 0) {
+        counters[0] = limit;
+        uint32_t flags = 0;
+        if (n_sel > (uint32_t)a.max_instances) flags |= 1u;      // VR_ERR_TOO_MANY_INSTANCES
+        if (overflow) flags |= 2u;                               // VR_ERR_OVERFLOW
+        counters[1] = flags;
+    }
+}
+
+int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
+{
+    SelectArgs a;
+    for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.loc[i] = t->p.location[i]; }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 4; j++) a.planes[i][j] = view->planes[i][j];
+    for (int i = 0; i < VR_MAX_LODS; i++) a.range2[i] = t->lod_ranges[i] * t->lod_ranges[i];
+    a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f;
+    a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.height_loaded = 0; a.max_height = max_height;
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters);
+    VR_HIP(hipGetLastError());
+    t->have_selection = true;
+    return VR_OK;
+}
+
+// ---- terrain object -------------------------------------------------------------------
+static int ilog2_floor(float x)
+{
+    uint32_t b; memcpy(&b, &x, 4);
+    return (int)((b >> 23) & 255u) - 127;
+}
+
+extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params* params, const uint8_t* height_r8,
+                                         int32_t hm_w, int32_t hm_h, const uint8_t* albedo, int32_t al_w, int32_t al_h,
+                                         vr_terrain** out)
+{
+    VR_REQUIRE(ctx && params && out, "NULL argument");
+    VR_REQUIRE(height_r8 && albedo, "heightmap/albedo missing (reference logs 'Heightmap texture data missing', QuadTree.cpp:39)");
+    VR_REQUIRE(params->grid_size == kGrid, "grid_size must be 32");
+    VR_REQUIRE(params->max_instances > 0 && params->max_instances <= 4096, "max_instances must be in 1..4096");
+    VR_REQUIRE(params->surface_size >= 1.0f && params->world_size >= params->surface_size, "bad surface/world size");
+    VR_REQUIRE(params->min_lod_distance > 0.0f && params->morph_start > 0.0f && params->morph_start < 1.0f, "bad LOD parameters");
+    VR_HIP(hipSetDevice(ctx->device));
+    vr_terrain* t = new vr_terrain();
+    t->ctx = ctx; t->p = *params;
+    // QuadTree::InitLodRanges (QuadTree.cpp:234-241), QuadTree::Init numLods (QuadTree.cpp:22)
+    for (int i = 0; i < VR_MAX_LODS; i++) t->lod_ranges[i] = params->min_lod_distance * powf(2.0f, (float)i);
+    int l2 = ilog2_floor(params->surface_size);
+    t->num_lods = (VR_MAX_LODS - 1) < l2 ? (VR_MAX_LODS - 1) : l2;
+    int rc;
+    if ((rc = vr_tex_upload_and_mip(ctx, height_r8, hm_w, hm_h, 1, &t->height, &t->d_height))) { vr_terrain_destroy(t); return rc; }
+    if ((rc = vr_tex_upload_and_mip(ctx, albedo, al_w, al_h, 4, &t->albedo, &t->d_albedo))) { vr_terrain_destroy(t); return rc; }
+    const size_t mi = (size_t)params->max_instances;
+    t->extra_vert_cap = 1u << 16; t->hard_cap = 1u << 15;
+#define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
+        vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); vr_terrain_destroy(t); return VR_ERR_OUT_OF_MEMORY; } } while (0)
+    VR_ALLOC(t->d_node_ids, mi * sizeof(uint32_t));
+    VR_ALLOC(t->d_instances, mi * sizeof(vr_instance));
+    VR_ALLOC(t->d_counters, 64 * sizeof(uint32_t));
+    VR_ALLOC(t->d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
+    VR_ALLOC(t->d_rect, mi * kTrisPerInst * sizeof(uint64_t));
+    VR_ALLOC(t->d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
+    VR_ALLOC(t->d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
+    VR_ALLOC(t->d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
+    t->bin_capacity = (size_t)16 << 20;
+    VR_ALLOC(t->d_bin_entries, t->bin_capacity * sizeof(uint32_t));
+#undef VR_ALLOC
+    VR_HIP(hipMemsetAsync(t->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+    *out = t;
+    return VR_OK;
+}
+
+extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_ids); (void)hipFree(t->d_instances);
+    (void)hipFree(t->d_counters); (void)hipFree(t->d_verts); (void)hipFree(t->d_rect); (void)hipFree(t->d_hard_list);
+    (void)hipFree(t->d_hard_tris); (void)hipFree(t->d_hard_first); (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_offset);
+    (void)hipFree(t->d_tile_cursor); (void)hipFree(t->d_bin_entries);
+    delete t;
+}
+
+extern "C" VR_API int vr_terrain_num_lods(const vr_terrain* t) { return t ? t->num_lods : -1; }
+extern "C" VR_API int vr_terrain_lod_ranges(const vr_terrain* t, float out[VR_MAX_LODS])
+{
+    VR_REQUIRE(t && out, "NULL argument");
+    for (int i = 0; i < VR_MAX_LODS; i++) out[i] = t->lod_ranges[i];
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_download_mip(vr_terrain* t, int which, int level, void* host, size_t bytes,
+                                               int32_t* w, int32_t* h, int32_t* levels)
+{
+    VR_REQUIRE(t && (which == 0 || which == 1), "bad arguments");
+    const DevTex& tx = which == 0 ? t->height : t->albedo;
+    if (levels) *levels = tx.levels;
+    VR_REQUIRE(level >= 0 && level < tx.levels, "mip level out of range");
+    const int lw = (tx.w0 >> level) > 1 ? (tx.w0 >> level) : 1, lh = (tx.h0 >> level) > 1 ? (tx.h0 >> level) : 1;
+    if (w) *w = lw;
+    if (h) *h = lh;
+    if (!host) return VR_OK;
+    const size_t nb = (size_t)lw * lh * (which == 0 ? 1 : 4);
+    VR_REQUIRE(bytes == nb, "byte count does not match the level size");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    uint32_t off[kMaxLevels];
+    VR_HIP(hipMemcpy(off, tx.off, sizeof(off), hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(host, tx.base + off[level], nb, hipMemcpyDeviceToHost));
+    return VR_OK;
+}
+
+static int read_counters(vr_terrain* t, uint32_t* count)
+{
+    uint32_t c[4] = { 0, 0, 0, 0 };
+    VR_HIP(hipMemcpyAsync(c, t->d_counters, sizeof(c), hipMemcpyDeviceToHost, t->ctx->stream));
+    VR_HIP(hipStreamSynchronize(t->ctx->stream));
+    if (count) *count = c[0];
+    if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
+    if (c[1] & 1u) { vr_set_error("more than max_instances nodes selected (TerrainPass.cpp:238 assert)"); return VR_ERR_TOO_MANY_INSTANCES; }
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, float max_height, uint32_t* node_ids,
+                                         vr_instance* instances, uint32_t* count)
+{
+    VR_REQUIRE(t && view, "NULL argument");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    int rc = vr_select_launch(t, view, max_height);
+    if (rc) return rc;
+    if (!node_ids && !instances && !count) return VR_OK;       // stays asynchronous
+    uint32_t n = 0;
+    rc = read_counters(t, &n);
+    if (count) *count = n;
+    if (node_ids && n) VR_HIP(hipMemcpy(node_ids, t->d_node_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (instances && n) VR_HIP(hipMemcpy(instances, t->d_instances, n * sizeof(vr_instance), hipMemcpyDeviceToHost));
+    return rc;
+}
+
+extern "C" VR_API int vr_terrain_num_chunks(vr_terrain* t, uint32_t* count)
+{
+    VR_REQUIRE(t && count, "NULL argument");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    if (!t->have_selection) { *count = 0; return VR_OK; }
+    return read_counters(t, count);
+}

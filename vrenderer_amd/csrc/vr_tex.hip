@@ -1,0 +1,165 @@
+// Texture upload + mip-chain generation on the device, and the synthetic input
+// generators (the reference's media/ directory is git-ignored: .gitignore:36,52).
+#include "vr_internal.h"
+#include "vr_tex_dev.h"
+
+// 2x2 box downsample of an R8_UNORM level: round(avg * 255) == (sum + 2) >> 2.
+__global__ void k_mip_r8(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    int x0 = 2 * x, x1 = min(2 * x + 1, sw - 1), y0 = 2 * y, y1 = min(2 * y + 1, sh - 1);
+    int sum = src[y0 * sw + x0] + src[y0 * sw + x1] + src[y1 * sw + x0] + src[y1 * sw + x1];
+    dst[y * dw + x] = (uint8_t)((sum + 2) >> 2);
+}
+
+// SRGBA8 level: decode to linear, average, re-encode (what a blit into an SRGBA8
+// render target does); alpha is linear.
+__global__ void k_mip_srgba8(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
+                             const float* __restrict__ lut_g, const float* __restrict__ thr_g)
+{
+    __shared__ float lut[256];
+    __shared__ float thr[256];
+    int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = tid; i < 256; i += blockDim.x * blockDim.y) { lut[i] = lut_g[i]; thr[i] = thr_g[i]; }
+    __syncthreads();
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    int x0 = 2 * x, x1 = min(2 * x + 1, sw - 1), y0 = 2 * y, y1 = min(2 * y + 1, sh - 1);
+    uint32_t p00 = src[(size_t)y0 * sw + x0], p10 = src[(size_t)y0 * sw + x1];
+    uint32_t p01 = src[(size_t)y1 * sw + x0], p11 = src[(size_t)y1 * sw + x1];
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int sh8 = 8 * c;
+        float a = (lut[(p00 >> sh8) & 255u] + lut[(p10 >> sh8) & 255u]) + (lut[(p01 >> sh8) & 255u] + lut[(p11 >> sh8) & 255u]);
+        o |= vr_srgb_encode(a * 0.25f, thr) << sh8;
+    }
+    uint32_t al = ((p00 >> 24) + (p10 >> 24) + (p01 >> 24) + (p11 >> 24) + 2u) >> 2;
+    dst[(size_t)y * dw + x] = o | (al << 24);
+}
+
+int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int tb, DevTex* out, uint8_t** out_mem)
+{
+    VR_REQUIRE(host && w > 0 && h > 0 && w <= 16384 && h <= 16384, "bad texture");
+    int levels = 1; { int m = w > h ? w : h; while (m > 1) { m >>= 1; levels++; } }
+    VR_REQUIRE(levels <= kMaxLevels, "too many mip levels");
+    uint32_t off[kMaxLevels] = { 0 };
+    size_t total = 0;
+    for (int l = 0; l < levels; l++) {
+        int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
+        off[l] = (uint32_t)total;
+        total += ((size_t)lw * lh * tb + 255) / 256 * 256;
+    }
+    size_t table_off = total;
+    total += sizeof(uint32_t) * kMaxLevels;
+    uint8_t* mem = nullptr;
+    VR_HIP(hipMalloc(&mem, total));
+    hipStream_t s = ctx->stream;
+    VR_HIP(hipMemcpyAsync(mem, host, (size_t)w * h * tb, hipMemcpyHostToDevice, s));
+    VR_HIP(hipMemcpyAsync(mem + table_off, off, sizeof(off), hipMemcpyHostToDevice, s));
+    int sw = w, sh = h;
+    for (int l = 1; l < levels; l++) {
+        int dw = sw > 1 ? sw >> 1 : 1, dh = sh > 1 ? sh >> 1 : 1;
+        dim3 blk(32, 8), grd((dw + 31) / 32, (dh + 7) / 8);
+        if (tb == 1) hipLaunchKernelGGL(k_mip_r8, grd, blk, 0, s, mem + off[l - 1], sw, sh, mem + off[l], dw, dh);
+        else hipLaunchKernelGGL(k_mip_srgba8, grd, blk, 0, s, (const uint32_t*)(mem + off[l - 1]), sw, sh,
+                                (uint32_t*)(mem + off[l]), dw, dh, ctx->d_srgb_lut, ctx->d_srgb_thr);
+        sw = dw; sh = dh;
+    }
+    VR_HIP(hipGetLastError());
+    VR_HIP(hipStreamSynchronize(s));   // host source buffer is caller-owned: finish the copy before returning
+    out->base = mem; out->off = (const uint32_t*)(mem + table_off); out->levels = levels; out->w0 = w; out->h0 = h; out->pad = 0;
+    *out_mem = mem;
+    return VR_OK;
+}
+
+// ---- synthetic inputs: integer-hash value-noise fBm (5 octaves) -> R8; height-banded
+// albedo + per-texel noise -> SRGBA8.  Integer arithmetic only. ------------------------
+__device__ __forceinline__ uint32_t vr_hash32(uint32_t x, uint32_t y, uint32_t s)
+{
+    uint32_t h = (x * 0x9E3779B1u) ^ (y * 0x85EBCA77u) ^ (s * 0xC2B2AE3Du);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+__device__ uint32_t vr_value_noise16(uint32_t x, uint32_t y, uint32_t period, uint32_t seed)
+{
+    uint32_t ix = x / period, iy = y / period;
+    uint32_t fx = ((x % period) << 16) / period, fy = ((y % period) << 16) / period;
+    uint64_t sx = ((((uint64_t)fx * fx) >> 16) * (uint64_t)(3u * 65536u - 2u * fx)) >> 16;
+    uint64_t sy = ((((uint64_t)fy * fy) >> 16) * (uint64_t)(3u * 65536u - 2u * fy)) >> 16;
+    uint64_t h00 = vr_hash32(ix, iy, seed) >> 16, h10 = vr_hash32(ix + 1, iy, seed) >> 16;
+    uint64_t h01 = vr_hash32(ix, iy + 1, seed) >> 16, h11 = vr_hash32(ix + 1, iy + 1, seed) >> 16;
+    uint64_t top = (h00 * (65536u - sx) + h10 * sx) >> 16;
+    uint64_t bot = (h01 * (65536u - sx) + h11 * sx) >> 16;
+    return (uint32_t)((top * (65536u - sy) + bot * sy) >> 16);
+}
+__global__ void k_synth_height(int size, uint32_t seed, uint8_t* out)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= size || y >= size) return;
+    const uint32_t wgt[5] = { 16, 8, 4, 2, 1 };
+    uint32_t total = 0;
+#pragma unroll
+    for (int o = 0; o < 5; o++) {
+        uint32_t period = (uint32_t)size >> (2 + o); if (period < 1) period = 1;
+        total += wgt[o] * vr_value_noise16((uint32_t)x, (uint32_t)y, period, seed + (uint32_t)o);
+    }
+    uint32_t v16 = total / 31u;
+    int32_t s = ((int32_t)v16 - 9000) * 3 / 2;
+    s = s < 0 ? 0 : (s > 65535 ? 65535 : s);
+    uint32_t h16 = ((uint32_t)s * (uint32_t)s) >> 16;
+    out[(size_t)y * size + x] = (uint8_t)(h16 >> 8);
+}
+__global__ void k_synth_albedo(int size, uint32_t seed, const uint8_t* height, uint32_t* out)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= size || y >= size) return;
+    const int32_t hs[6] = { 0, 20, 40, 110, 180, 255 };
+    const int32_t cs[6][3] = { { 40, 70, 110 }, { 60, 90, 120 }, { 180, 165, 120 }, { 70, 120, 50 }, { 110, 100, 90 }, { 235, 235, 240 } };
+    int32_t hgt = height[(size_t)y * size + x];
+    int seg = 0;
+    while (seg < 4 && hgt >= hs[seg + 1]) seg++;
+    int32_t h0 = hs[seg], h1 = hs[seg + 1];
+    uint32_t n = vr_hash32((uint32_t)x, (uint32_t)y, seed) & 255u;
+    uint32_t o = 0xff000000u;
+    for (int c = 0; c < 3; c++) {
+        int32_t v = (cs[seg][c] * (h1 - hgt) + cs[seg + 1][c] * (hgt - h0)) / (h1 - h0);
+        v += (int32_t)(n >> 4) - 8;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o |= (uint32_t)v << (8 * c);
+    }
+    out[(size_t)y * size + x] = o;
+}
+
+extern "C" VR_API int vr_synth_heightmap(vr_context* ctx, int32_t size, uint32_t seed, uint8_t* out)
+{
+    VR_REQUIRE(ctx && out && size >= 4 && size <= 16384, "bad arguments");
+    VR_HIP(hipSetDevice(ctx->device));
+    uint8_t* d = nullptr;
+    VR_HIP(hipMalloc(&d, (size_t)size * size));
+    dim3 blk(32, 8), grd((size + 31) / 32, (size + 7) / 8);
+    hipLaunchKernelGGL(k_synth_height, grd, blk, 0, ctx->stream, size, seed, d);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)size * size, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    VR_HIP(e);
+    return VR_OK;
+}
+extern "C" VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed, const uint8_t* height, uint8_t* out)
+{
+    VR_REQUIRE(ctx && out && height && size >= 4 && size <= 16384, "bad arguments");
+    VR_HIP(hipSetDevice(ctx->device));
+    uint8_t* dh = nullptr; uint32_t* dc = nullptr;
+    VR_HIP(hipMalloc(&dh, (size_t)size * size));
+    hipError_t e = hipMalloc(&dc, (size_t)size * size * 4);
+    if (e != hipSuccess) { (void)hipFree(dh); VR_HIP(e); }
+    e = hipMemcpyAsync(dh, height, (size_t)size * size, hipMemcpyHostToDevice, ctx->stream);
+    dim3 blk(32, 8), grd((size + 31) / 32, (size + 7) / 8);
+    hipLaunchKernelGGL(k_synth_albedo, grd, blk, 0, ctx->stream, size, seed, dh, dc);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dc, (size_t)size * size * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dh); (void)hipFree(dc);
+    VR_HIP(e);
+    return VR_OK;
+}

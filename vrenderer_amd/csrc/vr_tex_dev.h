@@ -1,0 +1,140 @@
+// Device-side texture sampling: what the linear-clamp sampler does for
+// terrain_vs.hlsl:32 (SampleLevel) and terrain_ps.hlsl:15,23 (Sample), in fp32
+// with explicit operation order and no contraction, plus the SRGBA8/SNORM16/half
+// render-target conversions.  There is no texture unit in this path: texels are
+// plain byte/dword loads that hit L2 / Infinity Cache (heightmap 5.3 MB, albedo
+// 21 MB with mips).
+#pragma once
+#include "vr_internal.h"
+#include <hip/hip_fp16.h>
+
+__device__ __forceinline__ int vr_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct BilinearSetup { int i00, i10, i01, i11; float fx, fy; };
+
+__device__ __forceinline__ BilinearSetup vr_bilinear_setup(int w, int h, float u, float v)
+{
+    BilinearSetup s;
+    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    s.fx = x - xf; s.fy = y - yf;
+    xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
+    int x0 = (int)xf, y0 = (int)yf;
+    int x1 = vr_clampi(x0 + 1, 0, w - 1), y1 = vr_clampi(y0 + 1, 0, h - 1);
+    x0 = vr_clampi(x0, 0, w - 1); y0 = vr_clampi(y0, 0, h - 1);
+    s.i00 = y0 * w + x0; s.i10 = y0 * w + x1; s.i01 = y1 * w + x0; s.i11 = y1 * w + x1;
+    return s;
+}
+
+__device__ __forceinline__ float vr_bilinear_r8(const DevTex& t, int level, float u, float v)
+{
+    int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
+    const uint8_t* d = t.base + t.off[level];
+    BilinearSetup s = vr_bilinear_setup(w, h, u, v);
+    float t00 = (float)d[s.i00] / 255.0f, t10 = (float)d[s.i10] / 255.0f;
+    float t01 = (float)d[s.i01] / 255.0f, t11 = (float)d[s.i11] / 255.0f;
+    float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
+    return top + (bot - top) * s.fy;
+}
+
+// lut: 256-entry sRGB8 -> linear table (LDS or global)
+__device__ __forceinline__ void vr_bilinear_srgb(const DevTex& t, int level, float u, float v, const float* lut, float out[3])
+{
+    int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
+    const uint32_t* d = (const uint32_t*)(t.base + t.off[level]);
+    BilinearSetup s = vr_bilinear_setup(w, h, u, v);
+    uint32_t p00 = d[s.i00], p10 = d[s.i10], p01 = d[s.i01], p11 = d[s.i11];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t00 = lut[(p00 >> (8 * c)) & 255u], t10 = lut[(p10 >> (8 * c)) & 255u];
+        float t01 = lut[(p01 >> (8 * c)) & 255u], t11 = lut[(p11 >> (8 * c)) & 255u];
+        float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
+        out[c] = top + (bot - top) * s.fy;
+    }
+}
+
+struct LodSplit { int l0; float f; };
+__device__ __forceinline__ LodSplit vr_lod_split(int levels, float lod)
+{
+    float maxl = (float)(levels - 1);
+    if (!(lod > 0.0f)) lod = 0.0f;
+    if (lod > maxl) lod = maxl;
+    float lf = floorf(lod);
+    LodSplit r; r.l0 = (int)lf; r.f = lod - lf;
+    return r;
+}
+
+__device__ __forceinline__ float vr_trilinear_r8(const DevTex& t, float lod, float u, float v)
+{
+    LodSplit ls = vr_lod_split(t.levels, lod);
+    float a = vr_bilinear_r8(t, ls.l0, u, v);
+    if (ls.f > 0.0f) {
+        float b = vr_bilinear_r8(t, ls.l0 + 1, u, v);
+        a = a + (b - a) * ls.f;
+    }
+    return a;
+}
+
+__device__ __forceinline__ void vr_trilinear_srgb(const DevTex& t, float lod, float u, float v, const float* lut, float out[3])
+{
+    LodSplit ls = vr_lod_split(t.levels, lod);
+    vr_bilinear_srgb(t, ls.l0, u, v, lut, out);
+    if (ls.f > 0.0f) {
+        float b[3];
+        vr_bilinear_srgb(t, ls.l0 + 1, u, v, lut, b);
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = out[c] + (b[c] - out[c]) * ls.f;
+    }
+}
+
+// Implicit LOD from screen-space uv differences (isotropic, D3D11 7.18.11) with the
+// pinned cubic log2 (max error 1.1e-3 LOD) so every implementation agrees exactly.
+__device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
+{
+    float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
+    float r2x = ax * ax + ay * ay, r2y = bx * bx + by * by;
+    float r2 = r2x > r2y ? r2x : r2y;
+    if (!(r2 > 1.0f)) return 0.0f;
+    uint32_t bits = __float_as_uint(r2);
+    int e = (int)((bits >> 23) & 255u) - 127;
+    if (e >= 128) return 64.0f;
+    float tt = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
+    float p = tt * (1.4208646f + tt * (-0.57725066f + tt * 0.1563861f));
+    return 0.5f * ((float)e + p);
+}
+
+// linear -> sRGB8: number of thresholds <= x (thr[0] = 0): round-to-nearest OETF.
+__device__ __forceinline__ uint32_t vr_srgb_encode(float x, const float* thr)
+{
+    if (!(x >= 0.0f)) return 0u;
+    int lo = 0, hi = 255;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        int mid = (lo + hi + 1) >> 1;
+        bool ge = x >= thr[mid];
+        lo = ge ? mid : lo; hi = ge ? hi : mid - 1;
+    }
+    return (uint32_t)lo;
+}
+
+__device__ __forceinline__ uint32_t vr_snorm16(float v)
+{
+    if (!(v == v)) return 0u;
+    v = vr_min(vr_max(v, -1.0f), 1.0f);
+    float s = v * 32767.0f;
+    int i = (int)(s >= 0.0f ? s + 0.5f : s - 0.5f);
+    return (uint32_t)i & 0xffffu;
+}
+__device__ __forceinline__ float vr_snorm16_decode(uint32_t u16)
+{
+    int s = (int)(int16_t)(uint16_t)u16;
+    return vr_max((float)s / 32767.0f, -1.0f);
+}
+__device__ __forceinline__ float vr_half_to_float(uint32_t h16)
+{
+    return __half2float(__ushort_as_half((unsigned short)h16));
+}
+__device__ __forceinline__ uint32_t vr_float_to_half(float f)
+{
+    return (uint32_t)__half_as_ushort(__float2half_rn(f));
+}

@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Names follow the reference (source/terrain/TerrainPass.h:133-159, QuadTree.h:94-118,
+Renderer.h:50-110, and DeferredLightingPass as called at Renderer.cpp:417-428); every
+method forwards to one C-ABI entry point of libvrterrain.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (GBufferDesc, Instance, Light, Partition, RenderParams, TerrainParams, View, check)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Context:
+    """nvrhi device + the frame's single command list (main.cpp:57-61, Renderer.cpp:48)."""
+
+    def __init__(self, device=0):
+        self.lib = capi.load_library()
+        h = C.c_void_p()
+        check(self.lib.vr_context_create(device, C.byref(h)), "vr_context_create")
+        self.handle = h
+        self.device = device
+
+    def set_stream(self, hip_stream):
+        check(self.lib.vr_context_set_stream(self.handle, C.c_void_p(hip_stream)), "vr_context_set_stream")
+
+    def synchronize(self):
+        check(self.lib.vr_context_synchronize(self.handle), "vr_context_synchronize")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vr_context_destroy(self.handle)
+            self.handle = None
+
+
+def default_terrain_params(size=2048.0):
+    """TerrainSettings (TerrainPass.h:23-30) with SURFACE_SIZE = WORLD_SIZE = size."""
+    p = TerrainParams()
+    capi.load_library().vr_terrain_default_params(C.byref(p))
+    p.surface_size = float(size)
+    p.world_size = float(size)
+    return p
+
+
+def default_render_params(max_height=400.0, **kw):
+    rp = RenderParams()
+    capi.load_library().vr_render_default_params(C.byref(rp))
+    rp.max_height = max_height
+    for k, v in kw.items():
+        setattr(rp, k, v)
+    return rp
+
+
+def make_view(eye, target, width, height, vfov_deg=60.0, z_near=0.1, z_far=10000.0, up=(0.0, 1.0, 0.0)):
+    """FirstPersonCamera::LookAt + perspProjD3DStyle(60 deg, aspect, 0.1, 10000) (Renderer.cpp:97,315)."""
+    v = View()
+    check(capi.load_library().vr_view_from_camera(_f3(eye), _f3(target), _f3(up),
+                                                  np.float32(np.radians(np.float32(vfov_deg))), z_near, z_far,
+                                                  width, height, C.byref(v)), "vr_view_from_camera")
+    return v
+
+
+def directional_light(direction, irradiance=1.0, angular_size_deg=0.53, color=(1.0, 1.0, 1.0)):
+    """DirectionalLight::FillLightConstants: normalised direction, angular size in radians."""
+    l = Light()
+    d = np.asarray(direction, np.float32)
+    d = d / np.float32(np.sqrt(np.float32((d * d).sum())))
+    l.direction[:] = [float(x) for x in d]
+    l.type = capi.VR_LIGHT_DIRECTIONAL
+    l.color[:] = [float(c) for c in color]
+    l.intensity = float(irradiance)
+    l.angular_size_or_inv_range = float(np.float32(np.radians(np.float32(angular_size_deg))))
+    return l
+
+
+def point_light(position, intensity, light_range, color=(1.0, 1.0, 1.0)):
+    l = Light()
+    l.type = capi.VR_LIGHT_POINT
+    l.position[:] = [float(x) for x in position]
+    l.color[:] = [float(c) for c in color]
+    l.intensity = float(intensity)
+    l.angular_size_or_inv_range = float(np.float32(1.0) / np.float32(light_range)) if light_range > 0 else 0.0
+    return l
+
+
+def reference_sun():
+    """The "Sun" Renderer::SceneLoaded creates (Renderer.cpp:133-146)."""
+    return directional_light((-0.9, -0.25, 0.35), irradiance=1.0, angular_size_deg=0.53)
+
+
+class RenderTargets:
+    """RenderTargets : GBufferRenderTargets (Renderer.h:50-110): Init / Clear."""
+
+    PLANES = {"depth": (0, np.float32, ()), "diffuse": (1, np.uint32, ()), "specular": (2, np.uint32, ()),
+              "normals": (3, np.uint16, (4,)), "emissive": (4, np.uint16, (4,))}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = None
+        self.width = self.height = 0
+
+    def Init(self, width, height):
+        self.close()
+        h = C.c_void_p()
+        check(self.ctx.lib.vr_gbuffer_create(self.ctx.handle, width, height, C.byref(h)), "vr_gbuffer_create")
+        self.handle, self.width, self.height = h, width, height
+        return self
+
+    def Clear(self):
+        check(self.ctx.lib.vr_gbuffer_clear(self.handle), "vr_gbuffer_clear")
+
+    def describe(self):
+        d = GBufferDesc()
+        check(self.ctx.lib.vr_gbuffer_describe(self.handle, C.byref(d)), "vr_gbuffer_describe")
+        return d
+
+    def download(self, plane):
+        idx, dt, tail = self.PLANES[plane]
+        out = np.empty((self.height, self.width) + tail, dt)
+        check(self.ctx.lib.vr_gbuffer_download(self.handle, idx, _vp(out), out.nbytes), "vr_gbuffer_download")
+        return out
+
+    def upload(self, plane, arr):
+        idx, dt, tail = self.PLANES[plane]
+        a = np.ascontiguousarray(arr, dt)
+        assert a.shape == (self.height, self.width) + tail
+        check(self.ctx.lib.vr_gbuffer_upload(self.handle, idx, _vp(a), a.nbytes), "vr_gbuffer_upload")
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.vr_gbuffer_destroy(self.handle)
+            self.handle = None
+
+
+class HdrImage:
+    """HdrColor, RGBA16_FLOAT (Renderer.h:69-79); optionally over caller-owned device memory."""
+
+    def __init__(self, ctx, width, height, external_ptr=None):
+        self.ctx, self.width, self.height = ctx, width, height
+        h = C.c_void_p()
+        check(ctx.lib.vr_image_create(ctx.handle, width, height, C.c_void_p(external_ptr) if external_ptr else None,
+                                      C.byref(h)), "vr_image_create")
+        self.handle = h
+
+    @property
+    def device_ptr(self):
+        return self.ctx.lib.vr_image_device_ptr(self.handle)
+
+    def download(self, nbytes=None):
+        n = nbytes if nbytes is not None else self.width * self.height * 8
+        out = np.empty(n // 2, np.uint16)
+        check(self.ctx.lib.vr_image_download(self.handle, _vp(out), n), "vr_image_download")
+        if nbytes is None:
+            return out.reshape(self.height, self.width, 4)
+        return out
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.vr_image_destroy(self.handle)
+            self.handle = None
+
+
+class TerrainPass:
+    """vRenderer::TerrainPass + its QuadTree (TerrainPass.h:32-159, QuadTree.h:64-127)."""
+
+    def __init__(self, ctx, params=None):
+        self.ctx = ctx
+        self.params = params or default_terrain_params()
+        self.handle = None
+
+    def Init(self, heightmap_r8, albedo_srgba8):
+        """TerrainPass::Init + QuadTree::Init (TerrainPass.cpp:34-141, QuadTree.cpp:19-52)."""
+        h = np.ascontiguousarray(heightmap_r8, np.uint8)
+        a = np.ascontiguousarray(albedo_srgba8, np.uint8)
+        assert h.ndim == 2 and a.ndim == 3 and a.shape[2] == 4
+        out = C.c_void_p()
+        check(self.ctx.lib.vr_terrain_create(self.ctx.handle, C.byref(self.params), _vp(h), h.shape[1], h.shape[0],
+                                             _vp(a), a.shape[1], a.shape[0], C.byref(out)), "vr_terrain_create")
+        self.handle = out
+        return self
+
+    def GetNumLods(self):
+        return self.ctx.lib.vr_terrain_num_lods(self.handle)
+
+    def GetLodRanges(self):
+        out = (C.c_float * capi.VR_MAX_LODS)()
+        check(self.ctx.lib.vr_terrain_lod_ranges(self.handle, out), "vr_terrain_lod_ranges")
+        return np.array(out[:], np.float32)
+
+    def download_mip(self, which, level):
+        """Read back one level of the device mip chain ('height' -> (h,w) u8, 'albedo' -> (h,w,4) u8)."""
+        idx = 0 if which == "height" else 1
+        w, h, lv = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.ctx.lib.vr_terrain_download_mip(self.handle, idx, level, None, 0, C.byref(w), C.byref(h), C.byref(lv)),
+              "vr_terrain_download_mip")
+        out = np.empty((h.value, w.value) if idx == 0 else (h.value, w.value, 4), np.uint8)
+        check(self.ctx.lib.vr_terrain_download_mip(self.handle, idx, level, _vp(out), out.nbytes, None, None, None),
+              "vr_terrain_download_mip")
+        return out
+
+    def mip_levels(self, which):
+        lv = C.c_int32()
+        check(self.ctx.lib.vr_terrain_download_mip(self.handle, 0 if which == "height" else 1, 0, None, 0, None, None,
+                                                   C.byref(lv)), "vr_terrain_download_mip")
+        return lv.value
+
+    def NodeSelect(self, view, max_height=400.0):
+        """ClearSelectedNodes + NodeSelect + UpdateTransforms (TerrainPass.cpp:173-190).
+
+        Returns (count, node_ids, instance bytes[count,112]) in m_SelectedNodes order."""
+        cap = self.params.max_instances
+        ids = np.zeros(cap, np.uint32)
+        inst = (Instance * cap)()
+        n = C.c_uint32()
+        check(self.ctx.lib.vr_terrain_select(self.handle, C.byref(view), max_height, _vp(ids), inst, C.byref(n)),
+              "vr_terrain_select")
+        k = n.value
+        return k, ids[:k].copy(), np.frombuffer(inst, dtype=np.uint8).reshape(cap, 112)[:k].copy()
+
+    def Render(self, view, view_prev, render_targets, render_params, partition=None):
+        """TerrainPass::Render (TerrainPass.cpp:143-232); asynchronous on the context's stream."""
+        check(self.ctx.lib.vr_terrain_render(self.handle, C.byref(view), C.byref(view_prev if view_prev is not None else view),
+                                             render_targets.handle, C.byref(render_params),
+                                             C.byref(partition) if partition is not None else None), "vr_terrain_render")
+
+    def num_chunks(self):
+        """EditorParams::m_NumChunks (TerrainPass.cpp:198); synchronises."""
+        n = C.c_uint32()
+        check(self.ctx.lib.vr_terrain_num_chunks(self.handle, C.byref(n)), "vr_terrain_num_chunks")
+        return n.value
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.vr_terrain_destroy(self.handle)
+            self.handle = None
+
+
+class DeferredLightingPass:
+    """donut::render::DeferredLightingPass as used at Renderer.cpp:239-240,417-428."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None):
+        n = len(lights)
+        arr = (Light * max(n, 1))(*lights)
+        check(self.ctx.lib.vr_deferred_light(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
+                                             _f3(ambient_top), _f3(ambient_bottom), output.handle,
+                                             C.byref(partition) if partition is not None else None), "vr_deferred_light")
+
+
+def synth_heightmap(ctx, size, seed=1337):
+    out = np.empty((size, size), np.uint8)
+    check(ctx.lib.vr_synth_heightmap(ctx.handle, size, seed, _vp(out)), "vr_synth_heightmap")
+    return out
+
+
+def synth_albedo(ctx, size, height, seed=4242):
+    h = np.ascontiguousarray(height, np.uint8)
+    out = np.empty((size, size, 4), np.uint8)
+    check(ctx.lib.vr_synth_albedo(ctx.handle, size, seed, _vp(h), _vp(out)), "vr_synth_albedo")
+    return out
+
+
+def partition_info(width, height, rank, world):
+    lib = capi.load_library()
+    p = Partition(rank, world)
+    tx, ty, owned, mo = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib.vr_partition_num_tiles(width, height, C.byref(p), C.byref(tx), C.byref(ty), C.byref(owned), C.byref(mo)),
+          "vr_partition_num_tiles")
+    return dict(tiles_x=tx.value, tiles_y=ty.value, owned=owned.value, max_owned=mo.value,
+                packed_bytes=lib.vr_partition_packed_bytes(width, height, world))
+
+
+def frame_detile(ctx, gathered_ptr, world, frame):
+    check(ctx.lib.vr_frame_detile(ctx.handle, C.c_void_p(gathered_ptr), world, frame.handle), "vr_frame_detile")
