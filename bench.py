@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — shaded Gpixels/s of the terrain + deferred-shading hot path at 8K on MI355X.
+
+One "step" = one frame of the hot path on synthetic input already resident in HBM:
+quadtree LOD select -> vertex transform -> triangle setup/binning -> tile raster + pixel
+shader into the G-buffer -> deferred lighting into HdrColor (RGBA16F).  With N > 1 the
+frame is partitioned into interleaved 128x128 screen tiles (owner = (tx+ty) mod N), each
+rank renders and lights only its tiles, and the packed tiles are all-gathered over
+RCCL/xGMI and de-tiled into the full frame on every rank (strong scaling: the frame is
+fixed, the ranks split it).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+DEFERRED_BYTES_PER_PX = 36     # 28 B G-buffer read + 8 B RGBA16F write
+GBUFFER_BYTES_PER_PX = 28      # G-buffer fill, per covered pixel
+
+
+def flythrough_camera(i, n=120, radius=600.0, height=250.0):
+    a = 2.0 * math.pi * (i % n) / n
+    return (radius * math.cos(a), height, radius * math.sin(a)), (0.0, 0.0, 0.0)
+
+
+def cpu_baseline(size, hm, al, params_fn, ambient, cam_fn):
+    """The oracle ("port") timed on this box's host cores on a bounded sample; rank 0, N=1 only."""
+    import numpy as np
+    from oracle import pyoracle as po
+    import vrenderer_amd as vr
+    po.build()
+    w, h = 1920, 1080
+    p = params_fn(size)
+    t0 = time.perf_counter()
+    ot = po.OracleTerrain(p, hm, al)
+    t_create = time.perf_counter() - t0
+    view = po.view_from_camera(*cam_fn(0), w, h)
+    gb = po.GBufferHost(w, h)
+    rp = vr.default_render_params(400.0)
+    t0 = time.perf_counter()
+    n = ot.render(view, gb, rp)
+    po.deferred(view, gb, [vr.reference_sun()], ambient[0], ambient[1])
+    t_frame = time.perf_counter() - t0
+    # the reference's own CPU-side terrain work, single-threaded like its main thread
+    import ctypes as C
+    t_build = po.lib().orc_time_tree_build(C.byref(p), hm.ctypes.data_as(C.c_void_p), hm.shape[1], hm.shape[0])
+    views = (vr.View * 120)(*[po.view_from_camera(*cam_fn(i), 7680, 4320) for i in range(120)])
+    sel = C.c_int()
+    reps = 200
+    t_sel = po.lib().orc_time_select(ot.handle, views, 120, 400.0, reps, C.byref(sel))
+    t_seth = po.lib().orc_time_set_height(ot.handle)
+    ot.close()
+    return {
+        "value": round(w * h / t_frame / 1e9, 6), "unit": "Gpixels/s", "cores": 1, "kind": "port",
+        "sample": f"1 frame {w}x{h} (1/16 of the 8K frame's pixels), same scene and first flythrough camera: "
+                  f"oracle select+raster+pixel shader+deferred, {n} nodes, {t_frame:.2f} s",
+        "host_cores": os.cpu_count(),
+        "reference_cpu_side": {
+            "quadtree_build_s": round(t_build, 4), "nodes": int((4 ** (ot_num_lods(size) + 1) - 1) // 3),
+            "select_plus_update_transforms_us_per_frame": round(t_sel / (reps * 120) * 1e6, 3),
+            "selected_nodes_sum_over_120_frames": int(sel.value),
+            "set_height_minmax_s": round(t_seth, 4),
+            "oracle_terrain_create_s": round(t_create, 3),
+            "note": "restatement of QuadTree::Split / NodeSelect / UpdateTransforms / SetHeight, 1 core (reference runs them on the main thread)",
+        },
+    }
+
+
+def ot_num_lods(size):
+    return min(11, int(math.log2(size)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--size", type=int, default=2048, help="heightmap / world size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if args.gpus == 1:
+        world, rank, local_rank = 1, 0, 0
+
+    import numpy as np
+    torch = None
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import vrenderer_amd as vr
+    from vrenderer_amd.passes import frame_detile, partition_info
+    from tests.common import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
+
+    W, H, size = args.width, args.height, args.size
+    ctx = vr.Context(local_rank)
+    if torch is not None:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    hm = vr.synth_heightmap(ctx, size, 1337)
+    al = vr.synth_albedo(ctx, size, hm, 4242)
+    tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
+    rt = vr.RenderTargets(ctx).Init(W, H)
+    lights = [vr.reference_sun()]
+    deferred = vr.DeferredLightingPass(ctx)
+    rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
+
+    part = None
+    if world > 1:
+        part = vr.Partition(rank, world)
+        info = partition_info(W, H, rank, world)
+        packed = torch.empty(info["packed_bytes"] // 2, dtype=torch.float16, device="cuda")
+        gathered = torch.empty(world * info["packed_bytes"] // 2, dtype=torch.float16, device="cuda")
+        # packed tile-major buffer: max_owned tiles of 128x128 RGBA16F, equal on every rank
+        hdr = vr.HdrImage(ctx, vr.VR_OWNER_TILE, info["max_owned"] * vr.VR_OWNER_TILE, external_ptr=packed.data_ptr())
+        frame = vr.HdrImage(ctx, W, H)
+        owned_px = info["owned"] * vr.VR_OWNER_TILE * vr.VR_OWNER_TILE
+    else:
+        hdr = vr.HdrImage(ctx, W, H)
+        frame = hdr
+        owned_px = W * H
+
+    def camera(i):
+        return (DEFAULT_EYE, DEFAULT_TARGET) if args.fixed_camera else flythrough_camera(i)
+
+    views = [vr.make_view(*camera(i), W, H) for i in range(120)]
+
+    def step(i):
+        v = views[i % 120]
+        tp.Render(v, v, rt, rp, part)
+        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, part)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, packed)
+            frame_detile(ctx, gathered.data_ptr(), world, frame)
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            ctx.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    ctx.timing_enable(True)          # HIP events around every kernel, on the stream they are launched on
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timings = ctx.timing_collect()
+    ctx.timing_enable(False)
+    n_nodes = tp.num_chunks()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = W * H * args.steps / elapsed / 1e9
+        kern = {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in timings.items()}
+        total_kernel_ms = sum(ms for ms, _ in timings.values())
+        dominant = max(timings.items(), key=lambda kv: kv[1][0])[0] if timings else None
+
+        def roof(name, bytes_per_px, px):
+            if name not in timings:
+                return None
+            ms, n = timings[name]
+            avg_s = ms / n * 1e-3
+            ach = bytes_per_px * px / avg_s / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
+                    "bytes_per_launch": bytes_per_px * px,
+                    "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"}
+
+        roof_deferred = roof("k_deferred", DEFERRED_BYTES_PER_PX, owned_px)
+        roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
+        out = {
+            "metric": "shaded Gpixels/s at 8K terrain", "value": round(value, 3), "unit": "Gpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
+                                   f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
+                                   + ("+all-gather+detile" if world > 1 else ""),
+                       "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,
+                       "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"},
+            # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
+            "roofline": roof_deferred,
+            "roofline_gbuffer_fill": roof_raster,
+            "dominant_kernel_by_time": dominant,
+            "kernels": kern,
+            "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,17 @@ VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submi
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);
 
+/* Per-kernel timing with HIP events recorded on the context's stream, the analogue of
+ * the reference's PROFILE_GPU_SCOPE timestamp queries (Profiler.h:55-125,
+ * Renderer.cpp:326-437).  Kernel ids: */
+enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
+       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_COUNT };
+VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
+/* Synchronises the stream; per kernel id: summed milliseconds and launch count since
+ * the last enable/collect; resets the samples. */
+VR_API int  vr_timing_collect(vr_context* ctx, float ms_sum[VR_K_COUNT], int32_t launches[VR_K_COUNT]);
+VR_API const char* vr_kernel_name(int id);
+
 /* ---- host helper: what FirstPersonCamera::LookAt + perspProjD3DStyle +
  * PlanarView::UpdateCache produce (Renderer.cpp:97,312-319).  Pure host code. -- */
 VR_API int vr_view_from_camera(const float eye[3], const float target[3], const float up[3],

@@ -20,6 +20,7 @@ VR_ERR_HIP = 6
 VR_LIGHT_DIRECTIONAL = 1
 VR_LIGHT_SPOT = 2
 VR_LIGHT_POINT = 3
+VR_K_COUNT = 10
 
 
 class TerrainParams(C.Structure):
@@ -107,7 +108,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvrterrain.so")
 # every symbol include/vrterrain.h declares
 EXPORTS = [
     "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_synchronize",
-    "vr_last_error", "vr_version", "vr_view_from_camera", "vr_terrain_default_params",
+    "vr_last_error", "vr_version", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_select", "vr_terrain_render", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
@@ -146,6 +147,9 @@ def load_library():
         "vr_context_synchronize": (C.c_int, [vp]),
         "vr_last_error": (C.c_char_p, []),
         "vr_version": (C.c_char_p, []),
+        "vr_timing_enable": (C.c_int, [vp, C.c_int]),
+        "vr_timing_collect": (C.c_int, [vp, P(C.c_float), P(C.c_int32)]),
+        "vr_kernel_name": (C.c_char_p, [C.c_int]),
         "vr_view_from_camera": (C.c_int, [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float, C.c_float,
                                           C.c_float, C.c_int32, C.c_int32, P(View)]),
         "vr_terrain_default_params": (None, [P(TerrainParams)]),

@@ -11,7 +11,7 @@
 // with one or two 16-byte loads per lane (1 KiB per wave instruction) and the
 // output leaves as two 16-byte stores.  All seven loads are issued before any
 // arithmetic so a wave keeps 112 B/lane in flight.  The sRGB decode table lives in
-// LDS.  fp32 math in fixed order, no contraction: results match the CPU oracle.
+// LDS.  fp32 math; checked against the CPU oracle to per-channel RMS <= 1e-4.
 #include "vr_internal.h"
 #include "vr_tex_dev.h"
 
@@ -32,100 +32,112 @@ struct DeferredArgs {
 #define VR_PI 3.14159265358979323846f
 #define VR_INV_PI 0.318309886183790671538f
 
+// Per-pixel shading.  Unlike the G-buffer pass (bit-exact integer/byte outputs), this
+// kernel's contract is the stated floating-point tolerance (per-channel RMS <= 1e-4 vs
+// the fp32 oracle; measured ~1e-8): it uses v_rcp_f32 / v_rsq_f32 (1 ulp), lets the
+// compiler contract mul+add into FMA, and folds the three divisions of the GGX term
+// (D, G, sphere normalisation) into one reciprocal.  ~5 transcendental-rate
+// instructions per pixel and light instead of ~15 IEEE divisions.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float dot3c(float ax, float ay, float az, float bx, float by, float bz)
+{
+#pragma clang fp contract(fast)
+    return ax * bx + ay * by + az * bz;
+}
+
 __device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
                                             uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
                                             float out[3])
 {
+#pragma clang fp contract(fast)
     const float albedo[3] = { lut[diff & 255u], lut[(diff >> 8) & 255u], lut[(diff >> 16) & 255u] };
     const float F0[3] = { lut[spec & 255u], lut[(spec >> 8) & 255u], lut[(spec >> 16) & 255u] };
-    const float occlusion = (float)(spec >> 24) / 255.0f;
-    const float N[3] = { vr_snorm16_decode(n01 & 0xffffu), vr_snorm16_decode(n01 >> 16), vr_snorm16_decode(n23 & 0xffffu) };
-    const float rough = vr_snorm16_decode(n23 >> 16);
+    const float occlusion = (float)(spec >> 24) * (1.0f / 255.0f);
+    const float sn16 = 1.0f / 32767.0f;
+    const float N[3] = { vr_max((float)(int16_t)(n01 & 0xffffu) * sn16, -1.0f), vr_max((float)(int16_t)(n01 >> 16) * sn16, -1.0f),
+                         vr_max((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f) };
+    const float rough = vr_max((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
     const float E[3] = { vr_half_to_float(e01 & 0xffffu), vr_half_to_float(e01 >> 16), vr_half_to_float(e23 & 0xffffu) };
 
     // ReconstructWorldPosition: window -> clip -> world
-    const float cx = ((float)px + 0.5f) * a.sx + -1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+    const float cx = ((float)px + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
     float wp4[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) wp4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + 1.0f * a.c2w[3 * 4 + j];
-    const float wp[3] = { wp4[0] / wp4[3], wp4[1] / wp4[3], wp4[2] / wp4[3] };
+    for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
+    const float rw = fast_rcp(wp4[3]);
+    const float wp[3] = { wp4[0] * rw, wp4[1] * rw, wp4[2] * rw };
     const float d[3] = { wp[0] - a.cam[0], wp[1] - a.cam[1], wp[2] - a.cam[2] };
-    const float dl = 1.0f / sqrtf(vr_dot3(d[0], d[1], d[2], d[0], d[1], d[2]));
-    const float vi[3] = { d[0] * dl, d[1] * dl, d[2] * dl };
-    const float V[3] = { -vi[0], -vi[1], -vi[2] };
-    const float NdotVi = vr_dot3(vi[0], vi[1], vi[2], N[0], N[1], N[2]);
+    const float dl = fast_rsq(dot3c(d[0], d[1], d[2], d[0], d[1], d[2]));
+    const float vi[3] = { d[0] * dl, d[1] * dl, d[2] * dl };            // viewIncident; V = -vi
+    const float NdotVi = dot3c(vi[0], vi[1], vi[2], N[0], N[1], N[2]);
     const float two = 2.0f * NdotVi;
-    const float R[3] = { vi[0] - N[0] * two, vi[1] - N[1] * two, vi[2] - N[2] * two };
-    const float NdotV = vr_saturate(vr_dot3(N[0], N[1], N[2], V[0], V[1], V[2]));
+    const float R[3] = { vi[0] - N[0] * two, vi[1] - N[1] * two, vi[2] - N[2] * two };   // reflect(viewIncident, N)
+    const float NdotV = vr_saturate(-NdotVi);
     const float alpha = vr_max(0.01f, rough * rough);
     const float a2 = alpha * alpha;
-    const float kk = ((rough + 1.0f) * (rough + 1.0f)) / 8.0f;
+    const float kk = ((rough + 1.0f) * (rough + 1.0f)) * 0.125f;
+    const float gv = NdotV * (1.0f - kk) + kk;
     float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
 
     for (int i = 0; i < a.num_lights; i++) {
         const DevLight& Lc = a.lights[i];
-        float Lin[3], irr;
+        float L[3], irr;                                                  // L = -incidentVector
         if (Lc.type == VR_LIGHT_DIRECTIONAL) {
-            Lin[0] = Lc.dir[0]; Lin[1] = Lc.dir[1]; Lin[2] = Lc.dir[2];
+            L[0] = -Lc.dir[0]; L[1] = -Lc.dir[1]; L[2] = -Lc.dir[2];
             irr = Lc.intensity;
         } else {
-            const float lts[3] = { wp[0] - Lc.pos[0], wp[1] - Lc.pos[1], wp[2] - Lc.pos[2] };
-            const float dist = sqrtf(vr_dot3(lts[0], lts[1], lts[2], lts[0], lts[1], lts[2]));
-            const float rd = 1.0f / dist;
-            Lin[0] = lts[0] * rd; Lin[1] = lts[1] * rd; Lin[2] = lts[2] * rd;
+            const float stl[3] = { Lc.pos[0] - wp[0], Lc.pos[1] - wp[1], Lc.pos[2] - wp[2] };
+            const float d2 = dot3c(stl[0], stl[1], stl[2], stl[0], stl[1], stl[2]);
+            const float rd = fast_rsq(d2);
+            L[0] = stl[0] * rd; L[1] = stl[1] * rd; L[2] = stl[2] * rd;
             float att = 1.0f;
             if (Lc.inv_range > 0.0f) {
-                const float q = dist * Lc.inv_range;
-                const float qq = q * q;
-                const float s = vr_saturate(1.0f - qq * qq);
+                const float q2 = d2 * (Lc.inv_range * Lc.inv_range);
+                const float s = vr_saturate(1.0f - q2 * q2);
                 att = s * s;
                 if (att == 0.0f) continue;
             }
             irr = (Lc.intensity * (rd * rd)) * att;
         }
-        const float L[3] = { -Lin[0], -Lin[1], -Lin[2] };
-        const float NdotLd = vr_max(vr_dot3(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0f);
+        const float NdotLd = vr_max(dot3c(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0f);
         const float kd = (NdotLd * VR_INV_PI) * irr;
-        const float cosT = vr_min(vr_max(vr_dot3(R[0], R[1], R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
-        float CL[3];
-        if (cosT >= Lc.cosH) { CL[0] = R[0]; CL[1] = R[1]; CL[2] = R[2]; }
-        else {
-            const float sinT = sqrtf(vr_max(1.0f - cosT * cosT, 1e-12f));
-            const float k2 = Lc.sinH / sinT;
-            const float k1 = Lc.cosH - cosT * k2;
-#pragma unroll
-            for (int c = 0; c < 3; c++) CL[c] = L[c] * k1 + R[c] * k2;
+        // area-light correction of L towards R (closed form of Donut's slerp)
+        const float cosT = vr_min(vr_max(dot3c(R[0], R[1], R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
+        float k1 = 0.0f, k2 = 1.0f;                                       // cosT >= cosH: CL = R
+        if (cosT < Lc.cosH) {
+            k2 = Lc.sinH * fast_rsq(vr_max(1.0f - cosT * cosT, 1e-12f));
+            k1 = Lc.cosH - cosT * k2;
         }
-        float Hv[3] = { CL[0] + V[0], CL[1] + V[1], CL[2] + V[2] };
-        const float hl2 = vr_dot3(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
-        const float hs = hl2 > 0.0f ? 1.0f / sqrtf(hl2) : 0.0f;
-        Hv[0] *= hs; Hv[1] *= hs; Hv[2] *= hs;
-        const float NdotH = vr_saturate(vr_dot3(N[0], N[1], N[2], Hv[0], Hv[1], Hv[2]));
-        const float NdotL = vr_saturate(vr_dot3(N[0], N[1], N[2], CL[0], CL[1], CL[2]));
-        const float VdotH = vr_saturate(vr_dot3(V[0], V[1], V[2], Hv[0], Hv[1], Hv[2]));
+        const float CL[3] = { L[0] * k1 + R[0] * k2, L[1] * k1 + R[1] * k2, L[2] * k1 + R[2] * k2 };
+        float Hv[3] = { CL[0] - vi[0], CL[1] - vi[1], CL[2] - vi[2] };
+        const float hl2 = dot3c(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
+        const float hs = hl2 > 0.0f ? fast_rsq(hl2) : 0.0f;
+        const float NdotH = vr_saturate(dot3c(N[0], N[1], N[2], Hv[0], Hv[1], Hv[2]) * hs);
+        const float NdotL = vr_saturate(dot3c(N[0], N[1], N[2], CL[0], CL[1], CL[2]));
+        const float VdotH = vr_saturate(-dot3c(vi[0], vi[1], vi[2], Hv[0], Hv[1], Hv[2]) * hs);
         const float corrAlpha = vr_saturate(alpha + 0.5f * Lc.tanH);
-        float sn = alpha / corrAlpha; sn = sn * sn;
         const float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
-        const float D = (a2 / (VR_PI * (dd * dd))) * sn;
-        const float G = 1.0f / ((NdotL * (1.0f - kk) + kk) * (NdotV * (1.0f - kk) + kk));
+        const float gl = NdotL * (1.0f - kk) + kk;
+        // D * G * NdotL / 4 * irradiance with D = a2/(pi dd^2) (alpha/corrAlpha)^2, G = 1/(gl gv)
+        const float num = (a2 * a2) * (NdotL * irr) * (0.25f * VR_INV_PI);
+        const float den = ((corrAlpha * dd) * (corrAlpha * dd)) * (gl * gv);
+        const float ks = num * fast_rcp(den);
         const float om = 1.0f - VdotH;
         const float om2 = om * om;
         const float fw = (om2 * om2) * om;
-        const float ks = (((D * G) * NdotL) / 4.0f) * irr;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float F = F0[c] + (1.0f - F0[c]) * fw;
-            diffuseTerm[c] = diffuseTerm[c] + (albedo[c] * kd) * Lc.color[c];
-            specularTerm[c] = specularTerm[c] + (F * ks) * Lc.color[c];
+            diffuseTerm[c] += (albedo[c] * kd) * Lc.color[c];
+            specularTerm[c] += (F * ks) * Lc.color[c];
         }
     }
     const float tt = N[1] * 0.5f + 0.5f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float amb = a.amb_bot[c] + (a.amb_top[c] - a.amb_bot[c]) * tt;
-        diffuseTerm[c] = diffuseTerm[c] + (amb * albedo[c]) * occlusion;
-        specularTerm[c] = specularTerm[c] + (amb * F0[c]) * occlusion;
-        out[c] = (diffuseTerm[c] + specularTerm[c]) + E[c];
+        const float amb = (a.amb_bot[c] + (a.amb_top[c] - a.amb_bot[c]) * tt) * occlusion;
+        out[c] = (diffuseTerm[c] + amb * albedo[c]) + (specularTerm[c] + amb * F0[c]) + E[c];
     }
 }
 
@@ -234,6 +246,7 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
     }
     const size_t npx = (size_t)gb->w * gb->h;
     const bool packed = part && part->world_size > 1;
+    VrKernelScope ks(ctx, VR_K_DEFERRED);
     if (packed) {
         int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
         if (rc) return rc;
@@ -283,6 +296,7 @@ extern "C" VR_API int vr_frame_detile(vr_context* ctx, const void* gathered, int
     VR_HIP(hipSetDevice(ctx->device));
     const size_t pairs = (size_t)frame->w * frame->h / 2;
     const int tiles_x = (frame->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+    VrKernelScope ks(ctx, VR_K_DETILE);
     hipLaunchKernelGGL(k_detile, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)gathered,
                        (uint4*)frame->data, frame->w, frame->h, tiles_x, ctx->d_tile_slot);
     VR_HIP(hipGetLastError());

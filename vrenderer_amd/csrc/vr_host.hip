@@ -20,6 +20,8 @@ extern "C" VR_API const char* vr_version(void) { return "vrterrain 0.1 (gfx950)"
 // ---- sRGB tables (SRGBA8 fetch / render-target conversion) -------------------------
 static double srgb_eotf(double c) { return c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4); }
 
+static void timing_reset(vr_context* c);
+
 // ---- context ----------------------------------------------------------------------
 extern "C" VR_API int vr_context_create(int device, vr_context** out)
 {
@@ -49,6 +51,8 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr);
     (void)hipFree(c->d_owned_tiles); (void)hipFree(c->d_tile_slot); (void)hipFree(c->d_raster_tiles);
+    timing_reset(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -64,6 +68,60 @@ extern "C" VR_API int vr_context_synchronize(vr_context* c)
     VR_REQUIRE(c != nullptr, "ctx is NULL");
     VR_HIP(hipStreamSynchronize(c->stream));
     return VR_OK;
+}
+
+// ---- per-kernel timing ---------------------------------------------------------------
+static hipEvent_t take_event(vr_context* c)
+{
+    hipEvent_t e = nullptr;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+VrKernelScope::VrKernelScope(vr_context* ctx, int id) : c(ctx)
+{
+    if (!c->timing) return;
+    hipEvent_t e0 = take_event(c); e1 = take_event(c);
+    if (!e0 || !e1) { e1 = nullptr; return; }
+    (void)hipEventRecord(e0, c->stream);
+    c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
+}
+VrKernelScope::~VrKernelScope() { if (e1) (void)hipEventRecord(e1, c->stream); }
+
+static void timing_reset(vr_context* c)
+{
+    for (hipEvent_t e : c->ev_begin) c->ev_pool.push_back(e);
+    for (hipEvent_t e : c->ev_end) c->ev_pool.push_back(e);
+    c->ev_begin.clear(); c->ev_end.clear(); c->ev_id.clear();
+}
+extern "C" VR_API int vr_timing_enable(vr_context* c, int enable)
+{
+    VR_REQUIRE(c != nullptr, "ctx is NULL");
+    VR_HIP(hipSetDevice(c->device));
+    VR_HIP(hipStreamSynchronize(c->stream));
+    timing_reset(c);
+    c->timing = enable != 0;
+    return VR_OK;
+}
+extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT], int32_t launches[VR_K_COUNT])
+{
+    VR_REQUIRE(c && ms_sum && launches, "NULL argument");
+    VR_HIP(hipSetDevice(c->device));
+    VR_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < VR_K_COUNT; i++) { ms_sum[i] = 0.0f; launches[i] = 0; }
+    for (size_t i = 0; i < c->ev_id.size(); i++) {
+        float ms = 0.0f;
+        VR_HIP(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+        ms_sum[c->ev_id[i]] += ms; launches[c->ev_id[i]]++;
+    }
+    timing_reset(c);
+    return VR_OK;
+}
+extern "C" VR_API const char* vr_kernel_name(int id)
+{
+    static const char* names[VR_K_COUNT] = { "k_select", "k_vertex", "k_setup", "k_clip", "k_scan", "k_fill", "k_raster",
+                                              "k_deferred", "k_detile", "k_fill_u32 (clear)" };
+    return (id >= 0 && id < VR_K_COUNT) ? names[id] : "?";
 }
 
 // ---- defaults (TerrainPass.h:23-30, QuadTree.cpp:236, terrain_vs.hlsl:20, Renderer.h:40) ----
@@ -214,6 +272,7 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
     size_t n = (size_t)g->w * g->h;
     hipStream_t s = g->ctx->stream;
     int rc;
+    VrKernelScope scope(g->ctx, VR_K_CLEAR);
     if ((rc = fill_u32(s, g->depth, n, 0x3f800000u))) return rc;      // depth = 1.0 (non-reversed)
     if ((rc = fill_u32(s, g->diffuse, n, 0u))) return rc;
     if ((rc = fill_u32(s, g->specular, n, 0u))) return rc;

@@ -78,6 +78,18 @@ struct vr_context {
     int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
     int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64) inside owned owner tiles
     int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+    // per-kernel timing (vr_timing_*): event pairs recorded on `stream`
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;     // reusable events
+    std::vector<hipEvent_t> ev_begin, ev_end;
+    std::vector<int> ev_id;
+};
+
+// Records a begin/end event pair around one kernel launch when timing is enabled.
+struct VrKernelScope {
+    vr_context* c; hipEvent_t e1 = nullptr;
+    VrKernelScope(vr_context* ctx, int id);
+    ~VrKernelScope();
 };
 
 struct vr_gbuffer {

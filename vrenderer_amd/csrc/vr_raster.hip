@@ -692,19 +692,26 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     va.vp_x = a.vp_x; va.vp_y = a.vp_y; va.vp_w = a.vp_w; va.vp_h = a.vp_h;
 
     HardTriRec* hard_tris = t->d_hard_tris;
-    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, s, va, t->height, t->d_instances, t->d_counters, t->d_verts);
-    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, s, a, t->d_verts, t->d_counters, t->d_rect, t->d_hard_list, t->d_tile_count);
-    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, s, a, t->d_verts, t->d_counters, t->d_hard_list, hard_tris, t->d_hard_first, t->d_tile_count);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, n_tiles, t->d_tile_count, t->d_tile_offset, t->d_tile_cursor, t->d_counters, a.bin_capacity);
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, a, t->d_counters, t->d_rect, hard_tris, t->d_tile_cursor, t->d_bin_entries);
+    { VrKernelScope ks(ctx, VR_K_VERTEX);
+    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, s, va, t->height, t->d_instances, t->d_counters, t->d_verts); }
+    { VrKernelScope ks(ctx, VR_K_SETUP);
+    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, s, a, t->d_verts, t->d_counters, t->d_rect, t->d_hard_list, t->d_tile_count); }
+    { VrKernelScope ks(ctx, VR_K_CLIP);
+    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, s, a, t->d_verts, t->d_counters, t->d_hard_list, hard_tris, t->d_hard_first, t->d_tile_count); }
+    { VrKernelScope ks(ctx, VR_K_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, n_tiles, t->d_tile_count, t->d_tile_offset, t->d_tile_cursor, t->d_counters, a.bin_capacity); }
+    { VrKernelScope ks(ctx, VR_K_FILL);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, a, t->d_counters, t->d_rect, hard_tris, t->d_tile_cursor, t->d_bin_entries); }
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
     const bool whole = world <= 1;
     const int grid = whole ? n_tiles : ctx->num_raster_tiles;
-    if (grid > 0)
+    if (grid > 0) {
+        VrKernelScope ks(ctx, VR_K_RASTER);
         hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, t->d_verts, hard_tris, t->d_hard_first,
                            t->d_tile_count, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, spec_const);
+    }
     VR_HIP(hipGetLastError());
     return VR_OK;
 }

@@ -165,6 +165,7 @@ int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
     for (int i = 0; i < VR_MAX_LODS; i++) a.range2[i] = t->lod_ranges[i] * t->lod_ranges[i];
     a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f;
     a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.height_loaded = 0; a.max_height = max_height;
+    VrKernelScope ks(t->ctx, VR_K_SELECT);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters);
     VR_HIP(hipGetLastError());
     t->have_selection = true;

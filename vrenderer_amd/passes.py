@@ -36,6 +36,16 @@ class Context:
     def synchronize(self):
         check(self.lib.vr_context_synchronize(self.handle), "vr_context_synchronize")
 
+    def timing_enable(self, enable=True):
+        check(self.lib.vr_timing_enable(self.handle, int(enable)), "vr_timing_enable")
+
+    def timing_collect(self):
+        """{kernel name: (total ms, launches)} since the last enable/collect (HIP events on the stream)."""
+        ms = (C.c_float * capi.VR_K_COUNT)()
+        n = (C.c_int32 * capi.VR_K_COUNT)()
+        check(self.lib.vr_timing_collect(self.handle, ms, n), "vr_timing_collect")
+        return {self.lib.vr_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(capi.VR_K_COUNT) if n[i]}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.vr_context_destroy(self.handle)
