@@ -41,7 +41,8 @@ struct RasterArgs {
     int mirrored;
     int world, rank;                // partition (world <= 1: whole frame)
     int depth_only, assume_cleared;
-    float world_size;
+    float world_size, inv_world_size;
+    int ws_pow2;                    // world_size is a power of two: x / ws == x * (1 / ws) exactly
     uint32_t bin_capacity;
     uint32_t extra_vert_base, extra_vert_cap, hard_cap;
     float vp_x, vp_y, vp_w, vp_h;
@@ -439,21 +440,50 @@ __device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVe
     return o;
 }
 
+// R8 texel taps with the UNORM8 -> float conversion (x / 255, correctly rounded) read from
+// an LDS table instead of 32 IEEE divisions per pixel; same values, bit for bit.
+__device__ __forceinline__ float bilinear_r8_lds(const DevTex& t, int level, float u, float v, const float* __restrict__ r8)
+{
+    const int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
+    const uint8_t* d = t.base + t.off[level];
+    const BilinearSetup s = vr_bilinear_setup(w, h, u, v);
+    const float t00 = r8[d[s.i00]], t10 = r8[d[s.i10]], t01 = r8[d[s.i01]], t11 = r8[d[s.i11]];
+    const float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
+    return top + (bot - top) * s.fy;
+}
+__device__ __forceinline__ float trilinear_r8_lds(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8)
+{
+    const LodSplit ls = vr_lod_split(t.levels, lod);
+    float a = bilinear_r8_lds(t, ls.l0, u, v, r8);
+    if (ls.f > 0.0f) {
+        const float b = bilinear_r8_lds(t, ls.l0 + 1, u, v, r8);
+        a = a + (b - a) * ls.f;
+    }
+    return a;
+}
+
+// (x + half) / world_size; when world_size is a power of two the division is an exact
+// scaling, so the multiplication by its reciprocal gives the identical float.
+__device__ __forceinline__ float to_uv(const RasterArgs& a, float x)
+{
+    const float s = x + a.world_size * 0.5f;
+    return a.ws_pow2 ? s * a.inv_world_size : s / a.world_size;
+}
+
 // main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
-                                             const float* __restrict__ thr, Attr p, Attr pr, Attr pd,
+                                             const float* __restrict__ thr, const float* __restrict__ r8, Attr p, Attr pr, Attr pd,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
-    const float halfSize = a.world_size * 0.5f, ws = a.world_size;
-    const float u = (p.wx + halfSize) / ws, v = (p.wz + halfSize) / ws;                     // :12-13, :20-21
-    const float ux = (pr.wx + halfSize) / ws, vx = (pr.wz + halfSize) / ws;
-    const float uy = (pd.wx + halfSize) / ws, vy = (pd.wz + halfSize) / ws;
+    const float u = to_uv(a, p.wx), v = to_uv(a, p.wz);                                      // :12-13, :20-21
+    const float ux = to_uv(a, pr.wx), vx = to_uv(a, pr.wz);
+    const float uy = to_uv(a, pd.wx), vy = to_uv(a, pd.wz);
     const float dudx = ux - u, dvdx = vx - v, dudy = uy - u, dvdy = vy - v;
     const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
     const float lod_c = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
     const float offset = 0.1f;                                                              // :59
-    const float hDx = vr_trilinear_r8(hm, lod_h, u + offset, v + 0.0f) - vr_trilinear_r8(hm, lod_h, u + (-offset), v + 0.0f);   // :60
-    const float hDy = vr_trilinear_r8(hm, lod_h, u + 0.0f, v + offset) - vr_trilinear_r8(hm, lod_h, u + 0.0f, v + (-offset));   // :61
+    const float hDx = trilinear_r8_lds(hm, lod_h, u + offset, v + 0.0f, r8) - trilinear_r8_lds(hm, lod_h, u + (-offset), v + 0.0f, r8);   // :60
+    const float hDy = trilinear_r8_lds(hm, lod_h, u + 0.0f, v + offset, r8) - trilinear_r8_lds(hm, lod_h, u + 0.0f, v + (-offset), r8);   // :61
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
     const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
     nx *= inv; ny *= inv; nz *= inv;
@@ -466,6 +496,59 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
 
 constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
 
+// Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
+// of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
+// When every value over the tile fits in 32 bits the sweep runs in int32, else in int64.
+template <typename T>
+__device__ __forceinline__ void cover_pixel(unsigned long long* __restrict__ vis, int lx, int ly, T v1, T v2, int b1, int b2,
+                                            float z0, float dz1, float dz2, float ia, uint32_t ord)
+{
+    const float l1 = (float)(v1 + (T)b1) * ia, l2 = (float)(v2 + (T)b2) * ia;
+    float z = (z0 + l1 * dz1) + l2 * dz2;
+    if (!(z >= 0.0f && z <= 1.0f)) return;                       // depth clip
+    z = z + 0.0f;                                                // canonical +0
+    atomicMin(&vis[ly * kRasterTile + lx], ((unsigned long long)__float_as_uint(z) << 32) | ord);
+}
+
+template <typename T>
+__device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
+                                            int b0, int b1, int b2, int x0, int y0, int x1, int y1,
+                                            float z0, float dz1, float dz2, float ia, uint32_t ord)
+{
+    for (int y = y0; y <= y1; y++) {
+        T r0 = e0 + sy0 * (T)y - (T)b0 + sx0 * (T)x0, r1 = e1 + sy1 * (T)y - (T)b1 + sx1 * (T)x0, r2 = e2 + sy2 * (T)y - (T)b2 + sx2 * (T)x0;
+        for (int x = x0; x <= x1; x++) {
+            if ((r0 | r1 | r2) >= 0) cover_pixel<T>(vis, x, y, r1, r2, b1, b2, z0, dz1, dz2, ia, ord);
+            r0 += sx0; r1 += sx1; r2 += sx2;
+        }
+    }
+}
+
+// All 64 lanes sweep one (wave-uniform) triangle in 8x8 pixel blocks; blocks that lie
+// completely outside an edge are skipped with scalar arithmetic only.
+template <typename T>
+__device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, int lane, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
+                                          int b0, int b1, int b2, int x0, int y0, int x1, int y1,
+                                          float z0, float dz1, float dz2, float ia, uint32_t ord)
+{
+    const int lx = lane & 7, ly = lane >> 3;
+    const T l0 = sx0 * (T)lx + sy0 * (T)ly, l1 = sx1 * (T)lx + sy1 * (T)ly, l2 = sx2 * (T)lx + sy2 * (T)ly;    // per-lane offsets
+    const T m0 = (sx0 > 0 ? sx0 * 7 : (T)0) + (sy0 > 0 ? sy0 * 7 : (T)0);                                      // max offset inside a block
+    const T m1 = (sx1 > 0 ? sx1 * 7 : (T)0) + (sy1 > 0 ? sy1 * 7 : (T)0);
+    const T m2 = (sx2 > 0 ? sx2 * 7 : (T)0) + (sy2 > 0 ? sy2 * 7 : (T)0);
+    for (int yb = y0 & ~7; yb <= y1; yb += 8) {
+        const T r0 = e0 - (T)b0 + sy0 * (T)yb, r1 = e1 - (T)b1 + sy1 * (T)yb, r2 = e2 - (T)b2 + sy2 * (T)yb;
+        for (int xb = x0 & ~7; xb <= x1; xb += 8) {
+            const T o0 = r0 + sx0 * (T)xb, o1 = r1 + sx1 * (T)xb, o2 = r2 + sx2 * (T)xb;                        // block origin (uniform)
+            if (((o0 + m0) | (o1 + m1) | (o2 + m2)) < 0) continue;                                              // block outside an edge
+            const T v0 = o0 + l0, v1 = o1 + l1, v2 = o2 + l2;
+            const int x = xb + lx, y = yb + ly;
+            if ((v0 | v1 | v2) < 0 || x < x0 || x > x1 || y < y0 || y > y1) continue;
+            cover_pixel<T>(vis, x, y, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
@@ -477,11 +560,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __shared__ unsigned long long vis[kRasterTile * kRasterTile];
     __shared__ float lut[256];
     __shared__ float thr[256];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ float r8[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * kRasterTile, oy = tyi * kRasterTile;
-    lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid];
+    lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     for (int i = tid; i < kRasterTile * kRasterTile; i += 256) {
         const int lx = i & (kRasterTile - 1), ly = i >> 6;
@@ -497,8 +581,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 
     const uint32_t n = tile_count[tile], off = tile_offset[tile];
     const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + kRasterTile - 1, a.vx1), by1 = min(oy + kRasterTile - 1, a.vy1);
+    const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
     for (uint32_t base = 0; base < n; base += 256) {
-        const uint32_t idx = base + (uint32_t)tid;
+        // consecutive bin entries go to different waves so that a short list still uses all four
+        const uint32_t idx = base + (uint32_t)(lane * 4 + wave);
         bool valid = idx < n && (off + idx) < a.bin_capacity;
         uint32_t key = 0;
         TriSetup t; t.visible = false;
@@ -511,54 +597,47 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         }
         valid = valid && t.visible;
         const uint32_t order = ~key;
-        const int bw = valid ? t.x1 - t.x0 + 1 : 0, bh = valid ? t.y1 - t.y0 + 1 : 0;
+        // tile-relative form
+        const int64_t e0 = edge_eval(t.A0, t.B0, t.C0, PX0, PY0), e1 = edge_eval(t.A1, t.B1, t.C1, PX0, PY0), e2 = edge_eval(t.A2, t.B2, t.C2, PX0, PY0);
+        const int64_t sx0 = (int64_t)t.A0 * 256, sy0 = (int64_t)t.B0 * 256, sx1 = (int64_t)t.A1 * 256, sy1 = (int64_t)t.B1 * 256;
+        const int64_t sx2 = (int64_t)t.A2 * 256, sy2 = (int64_t)t.B2 * 256;
+        const int64_t lim = (int64_t)1 << 30;
+        const int64_t span0 = (kRasterTile + 8) * (llabs(sx0) + llabs(sy0)), span1 = (kRasterTile + 8) * (llabs(sx1) + llabs(sy1));
+        const int64_t span2 = (kRasterTile + 8) * (llabs(sx2) + llabs(sy2));
+        const bool fits32 = valid && llabs(e0) + span0 < lim && llabs(e1) + span1 < lim && llabs(e2) + span2 < lim;
+        const int x0 = t.x0 - ox, y0 = t.y0 - oy, x1 = t.x1 - ox, y1 = t.y1 - oy;      // tile-local, inclusive
+        const int bw = valid ? x1 - x0 + 1 : 0, bh = valid ? y1 - y0 + 1 : 0;
         const bool small = valid && (bw * bh <= kSmallArea);
         if (small) {
-            for (int y = t.y0; y <= t.y1; y++) {
-                const int32_t PY = y * 256 + 128;
-                for (int x = t.x0; x <= t.x1; x++) {
-                    const int32_t PX = x * 256 + 128;
-                    const int64_t E0 = edge_eval(t.A0, t.B0, t.C0, PX, PY), E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
-                    if (E0 - t.bias0 < 0 || E1 - t.bias1 < 0 || E2 - t.bias2 < 0) continue;
-                    const float l1 = (float)E1 * t.inv_area, l2 = (float)E2 * t.inv_area;
-                    float z = (t.z0 + l1 * t.dz1) + l2 * t.dz2;
-                    if (!(z >= 0.0f && z <= 1.0f)) continue;
-                    z = z + 0.0f;                                   // canonical +0
-                    atomicMin(&vis[(y - oy) * kRasterTile + (x - ox)], ((unsigned long long)__float_as_uint(z) << 32) | order);
-                }
-            }
+            if (fits32) sweep_small<int32_t>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, (int32_t)sx0, (int32_t)sy0, (int32_t)sx1, (int32_t)sy1,
+                                             (int32_t)sx2, (int32_t)sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1, t.z0, t.dz1, t.dz2, t.inv_area, order);
+            else sweep_small<int64_t>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1,
+                                      t.z0, t.dz1, t.dz2, t.inv_area, order);
         }
-        // big triangles: broadcast one at a time, all 64 lanes sweep its bbox in 8x8 blocks
+        // big triangles: broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its bbox
         unsigned long long big = __ballot(valid && !small);
+        const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+        const uint32_t misc = (uint32_t)t.bias0 | ((uint32_t)t.bias1 << 1) | ((uint32_t)t.bias2 << 2) | (fits32 ? 8u : 0u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
 #define BC(v) __builtin_amdgcn_readlane((int)(v), src)
-            const int32_t A0 = BC(t.A0), B0 = BC(t.B0), A1 = BC(t.A1), B1 = BC(t.B1), A2 = BC(t.A2), B2 = BC(t.B2);
-            const int64_t C0 = ((int64_t)BC((int32_t)(t.C0 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C0);
-            const int64_t C1 = ((int64_t)BC((int32_t)(t.C1 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C1);
-            const int64_t C2 = ((int64_t)BC((int32_t)(t.C2 >> 32)) << 32) | (uint32_t)BC((int32_t)(uint32_t)t.C2);
-            const int32_t bb0 = BC(t.bias0), bb1 = BC(t.bias1), bb2 = BC(t.bias2);
+#define BC64(v) (((int64_t)BC((int32_t)((v) >> 32)) << 32) | (int64_t)(uint32_t)BC((int32_t)(uint32_t)(v)))
+            const uint32_t m = (uint32_t)BC(misc), bx = (uint32_t)BC(box), ord = (uint32_t)BC(order);
             const float z0 = __int_as_float(BC(__float_as_int(t.z0))), dz1 = __int_as_float(BC(__float_as_int(t.dz1)));
             const float dz2 = __int_as_float(BC(__float_as_int(t.dz2))), ia = __int_as_float(BC(__float_as_int(t.inv_area)));
-            const int x0 = BC(t.x0), y0 = BC(t.y0), x1 = BC(t.x1), y1 = BC(t.y1);
-            const uint32_t ord = (uint32_t)BC((int32_t)order);
-#undef BC
-            const int lx = lane & 7, ly = lane >> 3;
-            for (int yb = y0 & ~7; yb <= y1; yb += 8) {
-                for (int xb = x0 & ~7; xb <= x1; xb += 8) {
-                    const int x = xb + lx, y = yb + ly;
-                    if (x < x0 || x > x1 || y < y0 || y > y1) continue;
-                    const int32_t PX = x * 256 + 128, PY = y * 256 + 128;
-                    const int64_t E0 = edge_eval(A0, B0, C0, PX, PY), E1 = edge_eval(A1, B1, C1, PX, PY), E2 = edge_eval(A2, B2, C2, PX, PY);
-                    if (E0 - bb0 < 0 || E1 - bb1 < 0 || E2 - bb2 < 0) continue;
-                    const float l1 = (float)E1 * ia, l2 = (float)E2 * ia;
-                    float z = (z0 + l1 * dz1) + l2 * dz2;
-                    if (!(z >= 0.0f && z <= 1.0f)) continue;
-                    z = z + 0.0f;
-                    atomicMin(&vis[(y - oy) * kRasterTile + (x - ox)], ((unsigned long long)__float_as_uint(z) << 32) | ord);
-                }
+            const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
+            const int tx0 = bx & 255u, ty0 = (bx >> 8) & 255u, tx1 = (bx >> 16) & 255u, ty1 = bx >> 24;
+            if (m & 8u) {
+                sweep_big<int32_t>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC((int32_t)sx0), BC((int32_t)sy0),
+                                   BC((int32_t)sx1), BC((int32_t)sy1), BC((int32_t)sx2), BC((int32_t)sy2), b0, b1, b2, tx0, ty0, tx1, ty1,
+                                   z0, dz1, dz2, ia, ord);
+            } else {
+                sweep_big<int64_t>(vis, lane, BC64(e0), BC64(e1), BC64(e2), BC64(sx0), BC64(sy0), BC64(sx1), BC64(sy1), BC64(sx2), BC64(sy2),
+                                   b0, b1, b2, tx0, ty0, tx1, ty1, z0, dz1, dz2, ia, ord);
             }
+#undef BC64
+#undef BC
         }
     }
     __syncthreads();
@@ -571,6 +650,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         if (gy >= a.h || gx0 >= a.w) continue;
         uint32_t covered = 0;
         float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
+        uint32_t prev = 0xffffffffu;
+        ScreenVert s0, s1, s2; TriSetup t;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = vis[ly * kRasterTile + lx0 + k];
@@ -579,15 +660,19 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             if (low == 0xffffffffu || gx0 + k >= a.w) continue;
             covered |= 1u << k;
             if (a.depth_only) continue;
-            uint32_t i0, i1, i2;
-            entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
-            ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
-            TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+            if (low != prev) {                                    // neighbours usually share the triangle
+                uint32_t i0, i1, i2;
+                entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
+                s0 = load_sv(verts, i0); s1 = load_sv(verts, i1); s2 = load_sv(verts, i2);
+                t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+                prev = low;
+            }
             const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
-            const Attr p = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX, PY), edge_eval(t.A2, t.B2, t.C2, PX, PY));
-            const Attr pr = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX + 256, PY), edge_eval(t.A2, t.B2, t.C2, PX + 256, PY));
-            const Attr pd = interp_attr(s0, s1, s2, t.inv_area, edge_eval(t.A1, t.B1, t.C1, PX, PY + 256), edge_eval(t.A2, t.B2, t.C2, PX, PY + 256));
-            pixel_shader(a, hm, al, lut, thr, p, pr, pd, dif[k], nn0[k], nn1[k]);
+            const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
+            const Attr p = interp_attr(s0, s1, s2, t.inv_area, E1, E2);
+            const Attr pr = interp_attr(s0, s1, s2, t.inv_area, E1 + (int64_t)t.A1 * 256, E2 + (int64_t)t.A2 * 256);   // one pixel right
+            const Attr pd = interp_attr(s0, s1, s2, t.inv_area, E1 + (int64_t)t.B1 * 256, E2 + (int64_t)t.B2 * 256);   // one pixel down
+            pixel_shader(a, hm, al, lut, thr, r8, p, pr, pd, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);
@@ -666,7 +751,8 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     a.rtx = (gb->w + kRasterTile - 1) / kRasterTile; a.rty = (gb->h + kRasterTile - 1) / kRasterTile;
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared;
-    a.world_size = t->p.world_size;
+    a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
+    { uint32_t wb; memcpy(&wb, &t->p.world_size, 4); a.ws_pow2 = (wb & 0x7fffffu) == 0u && t->p.world_size >= 1.0f && t->p.world_size <= 65536.0f; }
     a.bin_capacity = (uint32_t)t->bin_capacity;
     a.extra_vert_base = (uint32_t)t->p.max_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
     a.vp_x = (float)view->viewport_x; a.vp_y = (float)view->viewport_y; a.vp_w = (float)view->viewport_w; a.vp_h = (float)view->viewport_h;
