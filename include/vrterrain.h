@@ -215,6 +215,7 @@ VR_API int  vr_image_create(vr_context* ctx, int32_t width, int32_t height,
 VR_API void vr_image_destroy(vr_image* img);
 VR_API void* vr_image_device_ptr(vr_image* img);
 VR_API int  vr_image_download(vr_image* img, void* host, size_t bytes);
+VR_API int  vr_image_upload(vr_image* img, const void* host, size_t bytes);
 
 /* ---- deferred lighting --------------------------------------------------------- */
 /* DeferredLightingPass::Render(cmd, view, Inputs{GBuffer, ambientColorTop/Bottom,

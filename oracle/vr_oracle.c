@@ -248,6 +248,7 @@ struct orc_terrain {
     /* select scratch */
     const orc_node** selected; int num_selected, cap_selected;
     int stub_frustum;
+    int have_selection;
 };
 
 /* QuadTree::InitLodRanges (QuadTree.cpp:234-241) */
@@ -439,6 +440,7 @@ int orc_select(orc_terrain* t, const vr_view* v, float max_height, int stub_frus
     t->stub_frustum = stub_frustum;
     float pos[3] = { v->camera_pos[0], v->camera_pos[1], v->camera_pos[2] };
     node_select(t, pos, t->root, t->num_lods, v, max_height);   /* TerrainPass.cpp:181 */
+    t->have_selection = 1;
     for (int i = 0; i < t->num_selected && i < capacity; i++) {
         if (node_ids) node_ids[i] = t->selected[i]->id;
         if (inst) update_transform(t->selected[i], &inst[i]);
@@ -819,7 +821,14 @@ int orc_render(orc_terrain* t, const vr_view* v, const vr_render_params* rp, con
     orc_target tg = { w, h, depth, diffuse, specular, normals, emissive, part, rp->depth_only };
     int cap = t->p.max_instances;
     vr_instance* inst = (vr_instance*)malloc(sizeof(vr_instance) * cap);
-    int n = orc_select(t, v, rp->max_height, 0, NULL, inst, cap);
+    int n;
+    if (rp->lock_view && t->have_selection) {
+        /* lockView: keep m_SelectedNodes and the instance buffer of the last unlocked frame (TerrainPass.cpp:173,191-197) */
+        n = t->num_selected;
+        for (int i = 0; i < n && i < cap; i++) update_transform(t->selected[i], &inst[i]);
+    } else {
+        n = orc_select(t, v, rp->max_height, 0, NULL, inst, cap);
+    }
     if (n > cap) n = cap;
     const int G = t->p.grid_size, S = G + 1;
     orc_vtx* verts = (orc_vtx*)malloc(sizeof(orc_vtx) * S * S);

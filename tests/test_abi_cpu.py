@@ -1,0 +1,119 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, its pure-host entry points behave, and it fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import vrenderer_amd as vr
+from vrenderer_amd import capi
+from vrenderer_amd import partition as pt
+from tests.common import DEFAULT_EYE, DEFAULT_TARGET
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu(lib):
+    h = C.c_void_p()
+    rc = lib.vr_context_create(0, C.byref(h))
+    if rc == capi.VR_OK:
+        lib.vr_context_destroy(h)
+        return True
+    return False
+
+
+def test_library_exports_every_declared_symbol(product_lib):
+    header = open(os.path.join(ROOT, "include", "vrterrain.h")).read()
+    declared = re.findall(r"VR_API\s+[\w\s\*]+?\b(vr_\w+)\s*\(", header)
+    assert len(declared) >= 30
+    assert sorted(set(declared)) == sorted(set(capi.EXPORTS)), "capi.EXPORTS and include/vrterrain.h disagree"
+    for name in declared:
+        assert hasattr(product_lib, name), name
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(capi.Instance) == 112 and C.sizeof(capi.Light) == 64
+    assert C.sizeof(capi.TerrainParams) == 40 and C.sizeof(capi.RenderParams) == 32
+    assert C.sizeof(capi.View) == 16 * 4 * 4 + 16 + 96 + 8 * 4
+    assert C.sizeof(capi.Partition) == 8
+
+
+def test_defaults_are_the_reference_settings(product_lib):
+    p = vr.default_terrain_params()
+    # TerrainSettings (TerrainPass.h:23-30), minLodDistance (QuadTree.cpp:236), morph start (terrain_vs.hlsl:20)
+    assert (p.max_instances, p.surface_size, p.world_size, p.grid_size) == (4096, 2048.0, 2048.0, 32)
+    assert p.min_lod_distance == 4.0 and abs(p.morph_start - 0.85) < 1e-7
+    rp = vr.default_render_params()
+    assert rp.max_height == 400.0 and not (rp.wireframe or rp.lock_view or rp.depth_only)   # Renderer.h:37-40
+
+
+def test_view_helper_matches_oracle_bit_for_bit(product_lib, oracle):
+    for (w, h) in ((1920, 1080), (7680, 4320), (333, 777)):
+        for eye, tgt in ((DEFAULT_EYE, DEFAULT_TARGET), ((600.0, 250.0, 0.0), (0.0, 0.0, 0.0)), ((3.0, 9.0, -4.0), (100.0, 0.0, 50.0))):
+            assert bytes(vr.make_view(eye, tgt, w, h)) == bytes(oracle.view_from_camera(eye, tgt, w, h))
+
+
+def test_view_helper_rejects_bad_arguments(product_lib):
+    v = vr.View()
+    f3 = (C.c_float * 3)(0, 0, 0)
+    assert product_lib.vr_view_from_camera(f3, f3, f3, 1.0, 0.1, 100.0, 0, 10, C.byref(v)) == capi.VR_ERR_INVALID_ARGUMENT
+    assert b"projection" in product_lib.vr_last_error()
+    assert product_lib.vr_view_from_camera(f3, f3, f3, 1.0, 1.0, 0.5, 10, 10, C.byref(v)) == capi.VR_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("w,h,world", [(7680, 4320, 8), (7680, 4320, 1), (3840, 2160, 4), (1920, 1080, 2), (300, 260, 3), (64, 64, 8)])
+def test_partition_tables_agree_with_python_mirror(product_lib, w, h, world):
+    tx, ty = pt.owner_grid(w, h)
+    counts = []
+    for r in range(world):
+        info = vr.passes.partition_info(w, h, r, world)
+        assert (info["tiles_x"], info["tiles_y"]) == (tx, ty)
+        assert info["owned"] == len(pt.owned_tiles(w, h, r, world))
+        assert info["max_owned"] == pt.max_owned(w, h, world)
+        assert info["packed_bytes"] == pt.max_owned(w, h, world) * 128 * 128 * 8
+        counts.append(info["owned"])
+    assert sum(counts) == tx * ty
+    if (w, h, world) == (7680, 4320, 8):
+        # 60 x 34 = 2,040 owner tiles, ~255 per rank (the diagonal interleave is balanced to within 2 tiles)
+        assert (tx, ty) == (60, 34) and max(counts) - min(counts) <= 2 and max(counts) == 256
+    slots = pt.tile_slots(w, h, world)
+    assert len(set(slots.tolist())) == tx * ty
+
+
+def test_fails_loudly_without_a_gpu(product_lib):
+    if _has_gpu(product_lib):
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert product_lib.vr_context_create(0, C.byref(h)) == capi.VR_ERR_NO_DEVICE
+    assert b"no HIP device" in product_lib.vr_last_error()
+    with pytest.raises(vr.VrError):
+        vr.Context(0)
+
+
+def test_missing_extension_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load_library()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under vrenderer_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "vrenderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) in ("build", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "vr_oracle" not in text and "pyoracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_pack_detile_roundtrip_numpy():
+    rng = np.random.default_rng(3)
+    for (w, h, world) in ((300, 260, 3), (512, 256, 2), (130, 70, 8)):
+        frame = rng.integers(0, 65535, (h, w, 4), dtype=np.uint16)
+        gathered = np.concatenate([pt.pack(frame, r, world) for r in range(world)], 0)
+        assert np.array_equal(pt.detile(gathered, w, h, world), frame)

@@ -159,3 +159,118 @@ def test_deferred_rms_within_stated_tolerance(scene256, oracle, gpu_ctx, cam_ind
     mism = out != ref16
     assert mism.mean() < 0.02, f"{mism.mean():.4f} of the half values differ"
     assert np.abs(got.astype(np.float64) - oracle.half_to_float(ref16)).max() <= 2.0 ** -10 * max(1e-3, float(got.max()))
+
+
+def test_golden_frame_on_gpu(scene256, oracle, gpu_ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_256x144.npz"))
+    w, h = 256, 144
+    v = vr.View.from_buffer_copy(g["view"].tobytes())
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    scene256["tp"].Render(v, v, rt, vr.default_render_params(400.0))
+    for name in ("depth", "diffuse", "specular", "normals", "emissive"):
+        assert np.array_equal(rt.download(name), g[name]), name
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    want = oracle.half_to_float(g["hdr"]).astype(np.float64)
+    assert np.sqrt(np.mean((got - want) ** 2)) <= 1e-4
+    hdr.close()
+    rt.close()
+
+
+def test_lock_view_reuses_previous_selection(scene256, oracle, gpu_ctx):
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 480, 270
+    va = vr.make_view(*scaled_camera(CAMERAS[0], 256), w, h)
+    vb = vr.make_view(*scaled_camera(CAMERAS[5], 256), w, h)
+    rp = vr.default_render_params(400.0)
+    rpl = vr.default_render_params(400.0, lock_view=1)
+    gb = oracle.GBufferHost(w, h)
+    ot.render(va, gb, rp)
+    gb.clear()
+    n_o = ot.render(vb, gb, rpl)                 # selection of view A drawn from view B
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    tp.Render(va, va, rt, rp)
+    rt.Clear()
+    tp.Render(vb, vb, rt, rpl)
+    assert tp.num_chunks() == n_o
+    _assert_gbuffer_equal(gb, {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}, "lock_view")
+    rt.close()
+
+
+def test_render_over_existing_depth(scene256, oracle, gpu_ctx):
+    """Without assume_cleared the pass depth-tests (LessOrEqual) against what the G-buffer already holds
+    (the reference draws terrain after the glTF GBufferFill pass, Renderer.cpp:384-415)."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 400, 240
+    v = vr.make_view(*scaled_camera(CAMERAS[0], 256), w, h)
+    rp = vr.default_render_params(400.0)
+    gb = oracle.GBufferHost(w, h)
+    ot.render(v, gb, rp)
+    # an occluder: the left half is closer than any terrain, a band equals the terrain depth exactly
+    pre = oracle.GBufferHost(w, h)
+    pre.depth[:, : w // 2] = 0.25
+    pre.diffuse[:, : w // 2] = 0x11223344
+    yy, xx = np.mgrid[0:h, 0:w]
+    band = (gb.depth < 1.0) & (xx >= w // 2) & (yy % 5 == 0)
+    assert band.sum() > 100
+    pre.depth[band] = gb.depth[band]
+    pre.diffuse[band] = 0x55667788
+    want = oracle.GBufferHost(w, h)
+    for a, b in zip(want.planes(), pre.planes()):
+        a[...] = b
+    ot.render(v, want, rp)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    for k, arr in (("depth", pre.depth), ("diffuse", pre.diffuse), ("specular", pre.specular), ("normals", pre.normals),
+                   ("emissive", pre.emissive)):
+        rt.upload(k, arr)
+    tp.Render(v, v, rt, rp)
+    planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+    _assert_gbuffer_equal(want, planes, "pre-filled depth")
+    assert (planes["diffuse"][:, : w // 2] == 0x11223344).all()
+    assert (planes["diffuse"][band] != 0x55667788).all(), "equal depth must pass LessOrEqual"
+    rt.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_partition_emulated_on_one_gpu_equals_unsplit(scene256, oracle, gpu_ctx, world):
+    """run every rank's share on one GPU, concatenate the packed buffers as the
+    all-gather would, de-tile, and compare with the unsplit frame byte for byte."""
+    from vrenderer_amd.passes import frame_detile, partition_info
+    tp = scene256["tp"]
+    w, h = 640, 400
+    v = vr.make_view(*scaled_camera(CAMERAS[5], 256), w, h)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    lights = [vr.reference_sun()]
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    full = vr.HdrImage(gpu_ctx, w, h)
+    tp.Render(v, v, rt, rp)
+    dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, full)
+    ref = full.download()
+    ref_depth = rt.download("depth")
+    info = partition_info(w, h, 0, world)
+    gathered = np.zeros(world * info["packed_bytes"] // 2, np.uint16)
+    seen = np.zeros((h, w), np.int32)
+    for r in range(world):
+        part = vr.Partition(r, world)
+        rt.Clear()
+        packed = vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+        tp.Render(v, v, rt, rp, part)
+        dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, packed, part)
+        gathered[r * info["packed_bytes"] // 2:(r + 1) * info["packed_bytes"] // 2] = packed.download(info["packed_bytes"])
+        d = rt.download("depth")
+        seen += (d.view(np.uint32) == ref_depth.view(np.uint32)) & (ref_depth < 1.0)
+        packed.close()
+    # every covered pixel was rendered by exactly one rank
+    assert (seen[ref_depth < 1.0] == 1).all()
+    # "all-gather": upload the concatenation, then de-tile on the device
+    big = vr.HdrImage(gpu_ctx, 128, world * info["max_owned"] * 128)
+    big.upload(gathered)
+    out = vr.HdrImage(gpu_ctx, w, h)
+    frame_detile(gpu_ctx, big.device_ptr, world, out)
+    got = out.download()
+    assert np.array_equal(got, ref)
+    for o in (big, out, full, rt):
+        o.close()

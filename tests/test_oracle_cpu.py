@@ -1,0 +1,291 @@
+"""CPU tests of the oracle itself: known answers, golden fixtures, structural properties.
+
+The reference has no tests or fixtures; what pins the oracle is (i) the node counts the
+survey measured on the reference's own QuadTree.cpp, (ii) closed-form
+known answers, (iii) an independent float64 numpy restatement of the shading model.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import vrenderer_amd as vr
+from tests.common import AMBIENT_BOTTOM, AMBIENT_TOP, CAMERAS, DEFAULT_EYE, DEFAULT_TARGET, params, scaled_camera
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def t256(oracle):
+    h = oracle.synth_heightmap(256)
+    a = oracle.synth_albedo(256, h)
+    t = oracle.OracleTerrain(params(256), h, a)
+    yield t
+    t.close()
+
+
+def test_reference_recorded_counts_256(oracle, t256):
+    # reference QuadTree.cpp, surface 256: 87,381 nodes, 8 LODs, 28 selected at the
+    # default camera with frustum.intersectsWith stubbed to "always intersects"
+    assert t256.num_lods == 8
+    assert t256.num_nodes == 87381
+    v = oracle.view_from_camera(DEFAULT_EYE, DEFAULT_TARGET, 1920, 1080)
+    n, ids, _ = t256.select(v, 400.0, stub_frustum=True)
+    assert n == 28
+
+
+def test_reference_recorded_counts_2048(oracle):
+    # surface 2048: 5,592,405 nodes, 11 LODs, 562 selected (frustum stubbed)
+    h = np.zeros((2048, 2048), np.uint8)
+    a = np.zeros((8, 8, 4), np.uint8)
+    t = oracle.OracleTerrain(params(2048), h, a)
+    assert t.num_lods == 11
+    assert t.num_nodes == 5592405
+    v = oracle.view_from_camera(DEFAULT_EYE, DEFAULT_TARGET, 1920, 1080)
+    n, _, _ = t.select(v, 400.0, stub_frustum=True)
+    assert n == 562
+    # watertightness: from the reference's default camera the 2048 terrain fills the frame, so
+    # any pixel left at the clear depth would be a crack between triangles / LOD levels
+    w, hh = 480, 270
+    v = oracle.view_from_camera(DEFAULT_EYE, DEFAULT_TARGET, w, hh)
+    gb = oracle.GBufferHost(w, hh)
+    t.render(v, gb, vr.default_render_params(400.0))
+    assert (gb.depth < 1.0).all()
+    t.close()
+
+
+def test_lod_ranges(t256):
+    # QuadTree::InitLodRanges: 4 * 2^i (QuadTree.cpp:234-241)
+    assert np.array_equal(t256.lod_ranges(), 4.0 * 2.0 ** np.arange(12, dtype=np.float32))
+
+
+def test_golden_select_ids(oracle, t256):
+    g = np.load(os.path.join(GOLD, "select_ids.npz"))
+    for ci, cam in enumerate(CAMERAS):
+        eye, tgt = scaled_camera(cam, 256)
+        v = oracle.view_from_camera(eye, tgt, 1920, 1080)
+        n, ids, _ = t256.select(v, 400.0)
+        assert np.array_equal(ids, g[f"ids_256_{ci}"]), ci
+
+
+def _decode_id(i):
+    d = 0
+    while (4 ** (d + 1) - 1) // 3 <= i:
+        d += 1
+    rel = i - (4 ** d - 1) // 3
+    return d, rel % (1 << d), rel // (1 << d)
+
+
+def test_selection_structure(oracle, t256):
+    """Selected nodes are pairwise disjoint subtrees in depth-first (TL,TR,BL,BR) order and the
+    instance transform is scaling(extents) * translation(position) (TerrainPass.cpp:245-249)."""
+    L = t256.num_lods
+    for cam in CAMERAS:
+        eye, tgt = scaled_camera(cam, 256)
+        v = oracle.view_from_camera(eye, tgt, 1920, 1080)
+        n, ids, inst = t256.select(v, 400.0)
+        keys = []
+        for k, i in enumerate(ids):
+            d, ix, iz = _decode_id(int(i))
+            path = 0
+            for l in range(d - 1, -1, -1):
+                bx, bz = (ix >> l) & 1, (iz >> l) & 1
+                c = (1 if bx else 0) if bz else (3 if bx else 2)
+                path = (path << 2) | c
+            keys.append((path << (2 * (L - d)), d))
+            ext = 128.0 / (1 << d)
+            tr = np.frombuffer(inst[k].tobytes(), np.float32, 12, 16)
+            assert tr[0] == ext and tr[10] == ext and tr[5] == 0.0
+            assert tr[3] == -128.0 + (ix + 0.5) * 2 * ext and tr[11] == -128.0 + (iz + 0.5) * 2 * ext
+            hdr = np.frombuffer(inst[k].tobytes(), np.uint32, 4, 0)
+            assert list(hdr) == [0, 0, 0, 1]
+        assert keys == sorted(keys), "not in depth-first order"
+        for (ka, da), (kb, db) in zip(keys, keys[1:]):
+            assert kb >= ka + (1 << (2 * (L - da))), "overlapping subtrees selected"
+
+
+def test_golden_frame_regression(oracle, t256):
+    g = np.load(os.path.join(GOLD, "frame_256x144.npz"))
+    w, h = 256, 144
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v = oracle.view_from_camera(eye, tgt, w, h)
+    assert bytes(v) == g["view"].tobytes()
+    gb = oracle.GBufferHost(w, h)
+    t256.render(v, gb, vr.default_render_params(400.0))
+    for name in ("depth", "diffuse", "specular", "normals", "emissive"):
+        assert np.array_equal(getattr(gb, name), g[name]), name
+    hdr = oracle.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)
+    assert np.array_equal(hdr, g["hdr"])
+
+
+def test_flat_terrain_known_answers(oracle):
+    """Flat heightmap => normal (0,1,0) and depth of a plane; constant albedo survives the sRGB round trip."""
+    size = 256
+    h = np.full((size, size), 77, np.uint8)
+    a = np.zeros((size, size, 4), np.uint8)
+    a[...] = (128, 64, 200, 255)
+    t = oracle.OracleTerrain(params(size), h, a)
+    w, hh = 320, 180
+    v = oracle.view_from_camera((0.0, 160.0, 30.0), (0.0, 120.0, 0.0), w, hh)
+    gb = oracle.GBufferHost(w, hh)
+    t.render(v, gb, vr.default_render_params(400.0))
+    cov = gb.depth < 1.0
+    assert cov.mean() > 0.9
+    n = gb.normals.view(np.int16)[cov]
+    assert (n[:, 0] == 0).all() and (n[:, 1] == 32767).all() and (n[:, 2] == 0).all() and (n[:, 3] == 32767).all()
+    assert (gb.diffuse[cov] == (128 | (64 << 8) | (200 << 16) | (255 << 24))).all()
+    assert (gb.specular[cov] == (25 | (25 << 8) | (25 << 16) | (255 << 24))).all()   # sRGB8(0.01) = 25
+    assert not gb.emissive.any()
+    # world height of the plane is 77/255*400; reconstruct it from depth at the image centre
+    y_plane = np.float32(77) / np.float32(255) * np.float32(400)
+    c2w = np.array(v.clip_to_world[:], np.float64).reshape(4, 4)
+    py, px = hh // 2, w // 2
+    clip = np.array([(px + 0.5) * 2 / w - 1, 1 - (py + 0.5) * 2 / hh, float(gb.depth[py, px]), 1.0])
+    wp = clip @ c2w
+    assert abs(wp[1] / wp[3] - float(y_plane)) < 0.05
+    # Lambert known answer: sun straight down, irradiance 1 -> diffuse = albedo / pi (+ ambient top)
+    sun = vr.directional_light((0.0, -1.0, 0.0), 1.0, 0.0)
+    out = oracle.deferred(v, gb, [sun], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), f32=True)
+    alb = np.array([oracle.lib().orc_srgb8_to_linear(c) for c in (128, 64, 200)])
+    # what is left after the Lambert term is the GGX lobe: F0 is grey (25,25,25), so it is the
+    # same small positive number in every channel
+    rest = out[py, px, :3].astype(np.float64) - alb / np.pi
+    assert np.all(rest > 0) and np.all(rest < 2e-3) and np.ptp(rest) < 1e-6
+    t.close()
+
+
+def _shade_numpy(view, gb, lights, amb_top, amb_bot, oracle):
+    """Independent float64 restatement of the deferred model (vectorised numpy)."""
+    h, w = gb.depth.shape
+    lut = np.array([oracle.lib().orc_srgb8_to_linear(c) for c in range(256)], np.float64)
+    alb = np.stack([lut[(gb.diffuse >> s) & 255] for s in (0, 8, 16)], -1)
+    f0 = np.stack([lut[(gb.specular >> s) & 255] for s in (0, 8, 16)], -1)
+    occ = (gb.specular >> 24).astype(np.float64) / 255.0
+    nn = np.maximum(gb.normals.view(np.int16).astype(np.float64) / 32767.0, -1.0)
+    N, rough = nn[..., :3], nn[..., 3]
+    E = gb.emissive.view(np.float16).astype(np.float64)[..., :3]
+    xs, ys = np.meshgrid(np.arange(w) + 0.5, np.arange(h) + 0.5)
+    clip = np.stack([xs * 2 / w - 1, 1 - ys * 2 / h, gb.depth.astype(np.float64), np.ones_like(xs)], -1)
+    wp4 = clip @ np.array(view.clip_to_world[:], np.float64).reshape(4, 4)
+    wp = wp4[..., :3] / wp4[..., 3:]
+    vi = wp - np.array(view.camera_pos[:3], np.float64)
+    vi /= np.linalg.norm(vi, axis=-1, keepdims=True)
+    V = -vi
+    R = vi - 2 * (vi * N).sum(-1, keepdims=True) * N
+    ndv = np.clip((N * V).sum(-1), 0, 1)
+    alpha = np.maximum(0.01, rough ** 2)
+    kk = (rough + 1) ** 2 / 8
+    dterm = np.zeros_like(alb)
+    sterm = np.zeros_like(alb)
+    for l in lights:
+        half = 0.5 * l.angular_size_or_inv_range if l.type == vr.VR_LIGHT_DIRECTIONAL else 0.0
+        if l.type == vr.VR_LIGHT_DIRECTIONAL:
+            L = -np.array(l.direction[:], np.float64) * np.ones_like(wp)
+            irr = l.intensity * np.ones(wp.shape[:2])
+        else:
+            lts = wp - np.array(l.position[:], np.float64)
+            dist = np.linalg.norm(lts, axis=-1)
+            L = -lts / dist[..., None]
+            att = np.ones_like(dist)
+            if l.angular_size_or_inv_range > 0:
+                att = np.clip(1 - (dist * l.angular_size_or_inv_range) ** 4, 0, 1) ** 2
+            irr = l.intensity / dist ** 2 * att
+        kd = np.maximum((N * L).sum(-1), 0) / np.pi * irr
+        cosT = np.clip((R * L).sum(-1), -1, 1)
+        ang = np.arccos(cosT)
+        tsl = np.clip(np.where(ang > 0, half / np.maximum(ang, 1e-30), 1.0), 0, 1)
+        # slerp(L, R, t)
+        st = np.sin(np.maximum(ang, 1e-12))
+        wa = np.where(ang > 1e-9, np.sin((1 - tsl) * ang) / st, 1 - tsl)
+        wb = np.where(ang > 1e-9, np.sin(tsl * ang) / st, tsl)
+        CL = wa[..., None] * L + wb[..., None] * R
+        H = CL + V
+        hn = np.linalg.norm(H, axis=-1, keepdims=True)
+        H = np.where(hn > 0, H / np.maximum(hn, 1e-300), 0)
+        ndh = np.clip((N * H).sum(-1), 0, 1)
+        ndl = np.clip((N * CL).sum(-1), 0, 1)
+        vdh = np.clip((V * H).sum(-1), 0, 1)
+        ca = np.clip(alpha + 0.5 * np.tan(half), 0, 1)
+        D = alpha ** 2 / (np.pi * (ndh ** 2 * (alpha ** 2 - 1) + 1) ** 2) * (alpha / ca) ** 2
+        G = 1 / ((ndl * (1 - kk) + kk) * (ndv * (1 - kk) + kk))
+        F = f0 + (1 - f0) * ((1 - vdh) ** 5)[..., None]
+        col = np.array(l.color[:], np.float64)
+        dterm += alb * kd[..., None] * col
+        sterm += F * (D * G * ndl / 4 * irr)[..., None] * col
+    t = N[..., 1] * 0.5 + 0.5
+    amb = np.array(amb_bot, np.float64) + (np.array(amb_top, np.float64) - np.array(amb_bot, np.float64)) * t[..., None]
+    dterm += amb * alb * occ[..., None]
+    sterm += amb * f0 * occ[..., None]
+    return dterm + sterm + E
+
+
+def test_deferred_matches_independent_float64_model(oracle):
+    """The C oracle's closed-form area-light correction equals the slerp formulation (float64 numpy)."""
+    g = np.load(os.path.join(GOLD, "frame_256x144.npz"))
+    gb = oracle.GBufferHost(256, 144)
+    for name in ("depth", "diffuse", "specular", "normals", "emissive"):
+        getattr(gb, name)[...] = g[name]
+    v = vr.View.from_buffer_copy(g["view"].tobytes())
+    lights = [vr.reference_sun(), vr.point_light((10.0, 40.0, -5.0), 3000.0, 120.0, (1.0, 0.5, 0.25))]
+    got = oracle.deferred(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)[..., :3]
+    want = _shade_numpy(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, oracle)
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_half_and_srgb_conversions(oracle):
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.normal(0, 1, 4000), rng.uniform(-70000, 70000, 2000), 10.0 ** rng.uniform(-9, 5, 3000),
+                        [0.0, -0.0, 65504.0, 65520.0, 1e-8, 6e-8, 5.96e-8, 2.98e-8, np.inf, -np.inf]]).astype(np.float32)
+    ours = np.array([oracle.lib().orc_float_to_half(float(v)) for v in x], np.uint16)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(ours, ref)
+    back = np.array([oracle.lib().orc_half_to_float(int(v)) for v in range(0, 65536, 7)], np.float32)
+    refb = np.arange(0, 65536, 7, dtype=np.uint16).view(np.float16).astype(np.float32)
+    assert np.array_equal(back.view(np.uint32)[~np.isnan(refb)], refb.view(np.uint32)[~np.isnan(refb)])
+    for c in range(256):
+        lin = oracle.lib().orc_srgb8_to_linear(c)
+        assert oracle.lib().orc_linear_to_srgb8(lin) == c
+    assert oracle.lib().orc_linear_to_srgb8(0.01) == 25
+    assert oracle.lib().orc_linear_to_srgb8(-1.0) == 0 and oracle.lib().orc_linear_to_srgb8(2.0) == 255
+
+
+def test_view_helper_sanity(oracle):
+    v = oracle.view_from_camera(DEFAULT_EYE, DEFAULT_TARGET, 1920, 1080)
+    m = np.array(v.world_to_view[:], np.float64).reshape(4, 4)
+    assert np.allclose(m[:3, :3].T @ m[:3, :3], np.eye(3), atol=1e-6)
+    assert v.mirrored == 1          # right = dir x up: left-handed view space (front = CCW)
+    tgt = np.array(DEFAULT_TARGET + (1.0,), np.float64)
+    for p in v.planes:
+        assert np.dot(p[:3], tgt[:3]) - p[3] < 0, "look-at target must be inside the frustum"
+    eye = np.array(DEFAULT_EYE)
+    assert np.dot(np.array(v.planes[0][:3]), eye) - v.planes[0][3] > 0, "eye is behind the near plane"
+    c2w = np.array(v.clip_to_world[:], np.float64).reshape(4, 4)
+    w2c = np.array(v.world_to_clip[:], np.float64).reshape(4, 4)
+    for p in ((1.0, 1.8, 0.0, 1.0), (-200.0, 50.0, -300.0, 1.0), (30.0, 120.0, 100.0, 1.0)):
+        c = np.array(p) @ w2c
+        q = (c / c[3]) @ c2w            # clip_to_world is stored in fp32: round trip to ~1e-3 relative
+        assert np.allclose(q[:3] / q[3], p[:3], rtol=2e-3, atol=0.3)
+
+
+def test_partitioned_render_equals_unsplit(oracle, t256):
+    from vrenderer_amd import partition as pt
+    w, h = 300, 260     # not a multiple of the tile size: exercises ragged edge tiles
+    eye, tgt = scaled_camera(CAMERAS[5], 256)
+    v = oracle.view_from_camera(eye, tgt, w, h)
+    rp = vr.default_render_params(400.0)
+    full = oracle.GBufferHost(w, h)
+    t256.render(v, full, rp)
+    world = 3
+    seen = np.zeros((h, w), np.int32)
+    for r in range(world):
+        gb = oracle.GBufferHost(w, h)
+        t256.render(v, gb, rp, vr.Partition(r, world))
+        tx, _ = pt.owner_grid(w, h)
+        own = np.zeros((h, w), bool)
+        for t in pt.owned_tiles(w, h, r, world):
+            own[(t // tx) * 128:(t // tx) * 128 + 128, (t % tx) * 128:(t % tx) * 128 + 128] = True
+        seen += own
+        assert np.array_equal(gb.depth[own], full.depth[own]) and np.array_equal(gb.diffuse[own], full.diffuse[own])
+        assert (gb.depth[~own] == 1.0).all() and not gb.diffuse[~own].any(), "a rank touched pixels it does not own"
+    assert (seen == 1).all()

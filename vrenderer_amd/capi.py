@@ -113,7 +113,7 @@ EXPORTS = [
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_select", "vr_terrain_render", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
-    "vr_image_device_ptr", "vr_image_download", "vr_deferred_light", "vr_partition_num_tiles",
+    "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo",
 ]
 
@@ -174,6 +174,7 @@ def load_library():
         "vr_image_destroy": (None, [vp]),
         "vr_image_device_ptr": (vp, [vp]),
         "vr_image_download": (C.c_int, [vp, vp, C.c_size_t]),
+        "vr_image_upload": (C.c_int, [vp, vp, C.c_size_t]),
         "vr_deferred_light": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
                                         vp, P(Partition)]),
         "vr_partition_num_tiles": (C.c_int, [C.c_int32, C.c_int32, P(Partition), P(C.c_int32), P(C.c_int32),

@@ -173,6 +173,10 @@ class HdrImage:
             return out.reshape(self.height, self.width, 4)
         return out
 
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        check(self.ctx.lib.vr_image_upload(self.handle, _vp(a), a.nbytes), "vr_image_upload")
+
     def close(self):
         if self.handle:
             self.ctx.lib.vr_image_destroy(self.handle)
