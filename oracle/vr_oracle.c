@@ -675,8 +675,13 @@ static inline int top_left(const orc_sv* a, const orc_sv* b)
     return (dy < 0) || (dy == 0 && dx > 0);
 }
 
-typedef struct { float wx, wz; } orc_attr;
-static orc_attr interp(const orc_sv* v0, const orc_sv* v1, const orc_sv* v2, float inv_area, int64_t E1, int64_t E2)
+/* Perspective-correct interpolation of world xz at a pixel centre, and its screen-space
+ * derivatives (per one-pixel step in x and y) — the analytic derivative of the same
+ * interpolant, which is what Texture2D::Sample's implicit LOD is computed from here
+ * (hardware takes quad finite differences; D3D leaves the method to the implementation). */
+typedef struct { float wx, wz, dwxdx, dwzdx, dwxdy, dwzdy; } orc_attr;
+static orc_attr interp(const orc_sv* v0, const orc_sv* v1, const orc_sv* v2, float inv_area, int64_t E1, int64_t E2,
+                       int64_t dE1dx, int64_t dE2dx, int64_t dE1dy, int64_t dE2dy)
 {
     float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
     float l0 = (1.0f - l1) - l2;
@@ -687,19 +692,27 @@ static orc_attr interp(const orc_sv* v0, const orc_sv* v1, const orc_sv* v2, flo
     orc_attr a;
     a.wx = (b0 * v0->wx + b1 * v1->wx) + b2 * v2->wx;
     a.wz = (b0 * v0->wz + b1 * v1->wz) + b2 * v2->wz;
+    for (int dir = 0; dir < 2; dir++) {
+        float dl1 = (float)(dir ? dE1dy : dE1dx) * inv_area, dl2 = (float)(dir ? dE2dy : dE2dx) * inv_area;
+        float dl0 = (0.0f - dl1) - dl2;
+        float dq0 = dl0 * v0->iw, dq1 = dl1 * v1->iw, dq2 = dl2 * v2->iw;
+        float dden = (dq0 + dq1) + dq2;
+        float nx = (dq0 * v0->wx + dq1 * v1->wx) + dq2 * v2->wx;
+        float nz = (dq0 * v0->wz + dq1 * v1->wz) + dq2 * v2->wz;
+        float dx = (nx - a.wx * dden) * r, dz = (nz - a.wz * dden) * r;
+        if (dir) { a.dwxdy = dx; a.dwzdy = dz; } else { a.dwxdx = dx; a.dwzdx = dz; }
+    }
     return a;
 }
 
-/* main_ps (terrain_ps.hlsl:45-82) for one pixel; p = world xz at the pixel centre,
- * px/py = the same attribute one pixel to the right / below (for implicit LOD). */
-static void pixel_shader(const orc_terrain* t, orc_attr p, orc_attr px, orc_attr py,
+/* main_ps (terrain_ps.hlsl:45-82) for one pixel; p = world xz at the pixel centre with its
+ * screen-space derivatives (for the implicit LOD of Sample). */
+static void pixel_shader(const orc_terrain* t, orc_attr p,
                          uint32_t* diffuse, uint32_t* specular, uint16_t normals[4], uint16_t emissive[4])
 {
     float halfSize = t->p.world_size * 0.5f, ws = t->p.world_size;
     float u = (p.wx + halfSize) / ws, v = (p.wz + halfSize) / ws;                      /* :12-13,20-21 */
-    float ux = (px.wx + halfSize) / ws, vx = (px.wz + halfSize) / ws;
-    float uy = (py.wx + halfSize) / ws, vy = (py.wz + halfSize) / ws;
-    float dudx = ux - u, dvdx = vx - v, dudy = uy - u, dvdy = vy - v;
+    float dudx = p.dwxdx / ws, dvdx = p.dwzdx / ws, dudy = p.dwxdy / ws, dvdy = p.dwzdy / ws;
     float lod_h = lod_from_derivs(dudx, dvdx, dudy, dvdy, t->height.w[0], t->height.h[0]);
     float lod_c = lod_from_derivs(dudx, dvdx, dudy, dvdy, t->albedo.w[0], t->albedo.h[0]);
     const float offset = 0.1f;                                                         /* :59 */
@@ -772,10 +785,11 @@ static void raster_triangle(const orc_terrain* t, const vr_view* view, orc_targe
         if (!(z <= tg->depth[idx])) continue;                     /* ComparisonFunc::LessOrEqual (TerrainPass.cpp:482) */
         tg->depth[idx] = z;
         if (tg->depth_only) continue;
-        orc_attr p  = interp(&s0, &s1, &s2, inv_area, E1, E2);
-        orc_attr pr = interp(&s0, &s1, &s2, inv_area, edge_fn(&s2, &s0, PX + 256, PY), edge_fn(&s0, &s1, PX + 256, PY));
-        orc_attr pd = interp(&s0, &s1, &s2, inv_area, edge_fn(&s2, &s0, PX, PY + 256), edge_fn(&s0, &s1, PX, PY + 256));
-        pixel_shader(t, p, pr, pd, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
+        /* per-pixel steps of E1 = edge(s2,s0) and E2 = edge(s0,s1) */
+        orc_attr p = interp(&s0, &s1, &s2, inv_area, E1, E2,
+                            -(int64_t)(s0.Y - s2.Y) * 256, -(int64_t)(s1.Y - s0.Y) * 256,
+                            (int64_t)(s0.X - s2.X) * 256, (int64_t)(s1.X - s0.X) * 256);
+        pixel_shader(t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
     }
 }
 

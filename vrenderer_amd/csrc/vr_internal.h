@@ -39,6 +39,11 @@ struct DevTex {
     int levels;
     int w0, h0;                 // level l is max(1, w0 >> l) x max(1, h0 >> l)
     int pad;
+    // R8 textures only: per level a (w+2) x (h+2) table of bilinear footprints.  Entry (ix, iy)
+    // packs the four clamp-addressed texels (x0,y0) (x1,y0) (x0,y1) (x1,y1) for floor(x) = ix-1,
+    // floor(y) = iy-1 into one dword, so a bilinear tap is ONE load instead of four byte loads.
+    const uint32_t* quad;
+    const uint32_t* qoff;       // device table: dword offset of each level's quad table
 };
 
 // Per-light constants the deferred kernel reads (host precomputes the half-angle terms).

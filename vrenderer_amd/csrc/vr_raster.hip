@@ -73,6 +73,9 @@ __device__ __forceinline__ void snap_vertex(DevVert& v, float vp_x, float vp_y, 
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const vr_instance* __restrict__ inst,
                                                  const uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
 {
+    __shared__ float r8[256];
+    r8[threadIdx.x] = (float)threadIdx.x / 255.0f;     // UNORM8 -> float, correctly rounded
+    __syncthreads();
     const uint32_t total = counters[C_COUNT] * (uint32_t)kVertsPerInst;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         const uint32_t i = v / kVertsPerInst, r = v - i * kVertsPerInst;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
         // sampleHeight (:27-33)
         const float halfSize = a.world_size * 0.5f;
         const float u = (world[0] + halfSize) / a.world_size, w_ = (world[2] + halfSize) / a.world_size;
-        world[1] = vr_trilinear_r8(hm, 0.1f, u, w_) * a.max_height;                                  // :51
+        world[1] = vr_trilinear_r8q(hm, 0.1f, u, w_, r8) * a.max_height;                                  // :51
         float viewPos[4], clip[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) viewPos[j] = ((world[0] * a.w2v[0 * 4 + j] + world[1] * a.w2v[1 * 4 + j]) + world[2] * a.w2v[2 * 4 + j]) + world[3] * a.w2v[3 * 4 + j];   // :60
@@ -425,8 +428,22 @@ __device__ __forceinline__ int64_t edge_eval(int32_t A, int32_t B, int64_t C, in
     return (int64_t)A * PX + ((int64_t)B * PY + C);
 }
 
-struct Attr { float wx, wz; };
-__device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, float inv_area, int64_t E1, int64_t E2)
+// Perspective-correct world xz at a pixel centre and its screen-space derivatives (analytic
+// derivative of the same interpolant; feeds the implicit LOD of Texture2D::Sample).
+struct Attr { float wx, wz, dwxdx, dwzdx, dwxdy, dwzdy; };
+struct TriDeriv { float dl1dx, dl2dx, dl1dy, dl2dy; };      // per-pixel steps of the barycentrics
+
+__device__ __forceinline__ TriDeriv tri_derivs(const TriSetup& t)
+{
+    // (float)(A * 256) == (float)A * 256 exactly (power-of-two scaling)
+    TriDeriv d;
+    d.dl1dx = ((float)t.A1 * 256.0f) * t.inv_area; d.dl2dx = ((float)t.A2 * 256.0f) * t.inv_area;
+    d.dl1dy = ((float)t.B1 * 256.0f) * t.inv_area; d.dl2dy = ((float)t.B2 * 256.0f) * t.inv_area;
+    return d;
+}
+
+__device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, float inv_area,
+                                            const TriDeriv& td, int64_t E1, int64_t E2)
 {
     const float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
     const float l0 = (1.0f - l1) - l2;
@@ -437,59 +454,50 @@ __device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVe
     Attr o;
     o.wx = (b0 * v0.wx + b1 * v1.wx) + b2 * v2.wx;
     o.wz = (b0 * v0.wz + b1 * v1.wz) + b2 * v2.wz;
-    return o;
-}
-
-// R8 texel taps with the UNORM8 -> float conversion (x / 255, correctly rounded) read from
-// an LDS table instead of 32 IEEE divisions per pixel; same values, bit for bit.
-__device__ __forceinline__ float bilinear_r8_lds(const DevTex& t, int level, float u, float v, const float* __restrict__ r8)
-{
-    const int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
-    const uint8_t* d = t.base + t.off[level];
-    const BilinearSetup s = vr_bilinear_setup(w, h, u, v);
-    const float t00 = r8[d[s.i00]], t10 = r8[d[s.i10]], t01 = r8[d[s.i01]], t11 = r8[d[s.i11]];
-    const float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
-    return top + (bot - top) * s.fy;
-}
-__device__ __forceinline__ float trilinear_r8_lds(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8)
-{
-    const LodSplit ls = vr_lod_split(t.levels, lod);
-    float a = bilinear_r8_lds(t, ls.l0, u, v, r8);
-    if (ls.f > 0.0f) {
-        const float b = bilinear_r8_lds(t, ls.l0 + 1, u, v, r8);
-        a = a + (b - a) * ls.f;
+    {
+        const float dl1 = td.dl1dx, dl2 = td.dl2dx, dl0 = (0.0f - dl1) - dl2;
+        const float dq0 = dl0 * v0.iw, dq1 = dl1 * v1.iw, dq2 = dl2 * v2.iw;
+        const float dden = (dq0 + dq1) + dq2;
+        const float nx = (dq0 * v0.wx + dq1 * v1.wx) + dq2 * v2.wx, nz = (dq0 * v0.wz + dq1 * v1.wz) + dq2 * v2.wz;
+        o.dwxdx = (nx - o.wx * dden) * r; o.dwzdx = (nz - o.wz * dden) * r;
     }
-    return a;
+    {
+        const float dl1 = td.dl1dy, dl2 = td.dl2dy, dl0 = (0.0f - dl1) - dl2;
+        const float dq0 = dl0 * v0.iw, dq1 = dl1 * v1.iw, dq2 = dl2 * v2.iw;
+        const float dden = (dq0 + dq1) + dq2;
+        const float nx = (dq0 * v0.wx + dq1 * v1.wx) + dq2 * v2.wx, nz = (dq0 * v0.wz + dq1 * v1.wz) + dq2 * v2.wz;
+        o.dwxdy = (nx - o.wx * dden) * r; o.dwzdy = (nz - o.wz * dden) * r;
+    }
+    return o;
 }
 
 // (x + half) / world_size; when world_size is a power of two the division is an exact
 // scaling, so the multiplication by its reciprocal gives the identical float.
-__device__ __forceinline__ float to_uv(const RasterArgs& a, float x)
+__device__ __forceinline__ float div_ws(const RasterArgs& a, float s)
 {
-    const float s = x + a.world_size * 0.5f;
     return a.ws_pow2 ? s * a.inv_world_size : s / a.world_size;
 }
+__device__ __forceinline__ float to_uv(const RasterArgs& a, float x) { return div_ws(a, x + a.world_size * 0.5f); }
 
 // main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
-                                             const float* __restrict__ thr, const float* __restrict__ r8, Attr p, Attr pr, Attr pd,
+                                             const float* __restrict__ thr, const float* __restrict__ r8, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
     const float u = to_uv(a, p.wx), v = to_uv(a, p.wz);                                      // :12-13, :20-21
-    const float ux = to_uv(a, pr.wx), vx = to_uv(a, pr.wz);
-    const float uy = to_uv(a, pd.wx), vy = to_uv(a, pd.wz);
-    const float dudx = ux - u, dvdx = vx - v, dudy = uy - u, dvdy = vy - v;
+    const float dudx = div_ws(a, p.dwxdx), dvdx = div_ws(a, p.dwzdx), dudy = div_ws(a, p.dwxdy), dvdy = div_ws(a, p.dwzdy);
     const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
-    const float lod_c = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
+    const float lod_c = (hm.w0 == al.w0 && hm.h0 == al.h0) ? lod_h : vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
     const float offset = 0.1f;                                                              // :59
-    const float hDx = trilinear_r8_lds(hm, lod_h, u + offset, v + 0.0f, r8) - trilinear_r8_lds(hm, lod_h, u + (-offset), v + 0.0f, r8);   // :60
-    const float hDy = trilinear_r8_lds(hm, lod_h, u + 0.0f, v + offset, r8) - trilinear_r8_lds(hm, lod_h, u + 0.0f, v + (-offset), r8);   // :61
+    const float hDx = vr_trilinear_r8q(hm, lod_h, u + offset, v + 0.0f, r8) - vr_trilinear_r8q(hm, lod_h, u + (-offset), v + 0.0f, r8);   // :60
+    const float hDy = vr_trilinear_r8q(hm, lod_h, u + 0.0f, v + offset, r8) - vr_trilinear_r8q(hm, lod_h, u + 0.0f, v + (-offset), r8);   // :61
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
     const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
     nx *= inv; ny *= inv; nz *= inv;
     float col[3];
     vr_trilinear_srgb(al, lod_c, u, v, lut, col);                                           // :68
-    diffuse = vr_srgb_encode(col[0], thr) | (vr_srgb_encode(col[1], thr) << 8) | (vr_srgb_encode(col[2], thr) << 16) | 0xff000000u;   // :73-75
+    diffuse = vr_srgb_encode_fast(col[0], thr) | (vr_srgb_encode_fast(col[1], thr) << 8) | (vr_srgb_encode_fast(col[2], thr) << 16)
+            | 0xff000000u;                                                                  // :73-75
     n01 = vr_snorm16(nx) | (vr_snorm16(ny) << 16);                                          // :78
     n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
 }
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         uint32_t covered = 0;
         float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
         uint32_t prev = 0xffffffffu;
-        ScreenVert s0, s1, s2; TriSetup t;
+        ScreenVert s0, s1, s2; TriSetup t; TriDeriv td;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = vis[ly * kRasterTile + lx0 + k];
@@ -665,14 +673,13 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
                 s0 = load_sv(verts, i0); s1 = load_sv(verts, i1); s2 = load_sv(verts, i2);
                 t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+                td = tri_derivs(t);
                 prev = low;
             }
             const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
             const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
-            const Attr p = interp_attr(s0, s1, s2, t.inv_area, E1, E2);
-            const Attr pr = interp_attr(s0, s1, s2, t.inv_area, E1 + (int64_t)t.A1 * 256, E2 + (int64_t)t.A2 * 256);   // one pixel right
-            const Attr pd = interp_attr(s0, s1, s2, t.inv_area, E1 + (int64_t)t.B1 * 256, E2 + (int64_t)t.B2 * 256);   // one pixel down
-            pixel_shader(a, hm, al, lut, thr, r8, p, pr, pd, dif[k], nn0[k], nn1[k]);
+            const Attr p = interp_attr(s0, s1, s2, t.inv_area, td, E1, E2);
+            pixel_shader(a, hm, al, lut, thr, r8, p, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);

@@ -39,6 +39,16 @@ __global__ void k_mip_srgba8(const uint32_t* __restrict__ src, int sw, int sh, u
     dst[(size_t)y * dw + x] = o | (al << 24);
 }
 
+__global__ void k_build_quads(const uint8_t* __restrict__ src, int w, int h, uint32_t* __restrict__ dst)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= w + 2 || iy >= h + 2) return;
+    const int x0 = min(max(ix - 1, 0), w - 1), x1 = min(max(ix, 0), w - 1);
+    const int y0 = min(max(iy - 1, 0), h - 1), y1 = min(max(iy, 0), h - 1);
+    dst[(size_t)iy * (w + 2) + ix] = (uint32_t)src[y0 * w + x0] | ((uint32_t)src[y0 * w + x1] << 8)
+                                   | ((uint32_t)src[y1 * w + x0] << 16) | ((uint32_t)src[y1 * w + x1] << 24);
+}
+
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int tb, DevTex* out, uint8_t** out_mem)
 {
     VR_REQUIRE(host && w > 0 && h > 0 && w <= 16384 && h <= 16384, "bad texture");
@@ -53,6 +63,19 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
     }
     size_t table_off = total;
     total += sizeof(uint32_t) * kMaxLevels;
+    // quad (bilinear footprint) tables for R8 textures
+    uint32_t qoff[kMaxLevels] = { 0 };
+    size_t qtable_off = 0, quad_off = 0, quad_dwords = 0;
+    if (tb == 1) {
+        for (int l = 0; l < levels; l++) {
+            int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
+            qoff[l] = (uint32_t)quad_dwords;
+            quad_dwords += ((size_t)(lw + 2) * (lh + 2) + 63) / 64 * 64;
+        }
+        qtable_off = total; total += sizeof(uint32_t) * kMaxLevels;
+        total = (total + 255) / 256 * 256;
+        quad_off = total; total += quad_dwords * sizeof(uint32_t);
+    }
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
     hipStream_t s = ctx->stream;
@@ -66,6 +89,16 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         else hipLaunchKernelGGL(k_mip_srgba8, grd, blk, 0, s, (const uint32_t*)(mem + off[l - 1]), sw, sh,
                                 (uint32_t*)(mem + off[l]), dw, dh, ctx->d_srgb_lut, ctx->d_srgb_thr);
         sw = dw; sh = dh;
+    }
+    out->quad = nullptr; out->qoff = nullptr;
+    if (tb == 1) {
+        VR_HIP(hipMemcpyAsync(mem + qtable_off, qoff, sizeof(qoff), hipMemcpyHostToDevice, s));
+        for (int l = 0; l < levels; l++) {
+            int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
+            dim3 blk(32, 8), grd((lw + 2 + 31) / 32, (lh + 2 + 7) / 8);
+            hipLaunchKernelGGL(k_build_quads, grd, blk, 0, s, mem + off[l], lw, lh, (uint32_t*)(mem + quad_off) + qoff[l]);
+        }
+        out->quad = (const uint32_t*)(mem + quad_off); out->qoff = (const uint32_t*)(mem + qtable_off);
     }
     VR_HIP(hipGetLastError());
     VR_HIP(hipStreamSynchronize(s));   // host source buffer is caller-owned: finish the copy before returning

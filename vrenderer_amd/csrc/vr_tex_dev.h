@@ -37,6 +37,22 @@ __device__ __forceinline__ float vr_bilinear_r8(const DevTex& t, int level, floa
     return top + (bot - top) * s.fy;
 }
 
+// R8 bilinear tap through the quad (footprint) table: one dword load; r8 = LDS table of i/255.
+__device__ __forceinline__ float vr_bilinear_r8q(const DevTex& t, int level, float u, float v, const float* __restrict__ r8)
+{
+    const int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
+    const int ix = (int)xf + 1, iy = (int)yf + 1;
+    const uint32_t e = t.quad[t.qoff[level] + (uint32_t)(iy * (w + 2) + ix)];
+    const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
+    const float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
+    return top + (bot - top) * fy;
+}
+__device__ __forceinline__ float vr_trilinear_r8q(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8);
+
 // lut: 256-entry sRGB8 -> linear table (LDS or global)
 __device__ __forceinline__ void vr_bilinear_srgb(const DevTex& t, int level, float u, float v, const float* lut, float out[3])
 {
@@ -87,6 +103,17 @@ __device__ __forceinline__ void vr_trilinear_srgb(const DevTex& t, float lod, fl
     }
 }
 
+__device__ __forceinline__ float vr_trilinear_r8q(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8)
+{
+    const LodSplit ls = vr_lod_split(t.levels, lod);
+    float a = vr_bilinear_r8q(t, ls.l0, u, v, r8);
+    if (ls.f > 0.0f) {
+        const float b = vr_bilinear_r8q(t, ls.l0 + 1, u, v, r8);
+        a = a + (b - a) * ls.f;
+    }
+    return a;
+}
+
 // Implicit LOD from screen-space uv differences (isotropic, D3D11 7.18.11) with the
 // pinned cubic log2 (max error 1.1e-3 LOD) so every implementation agrees exactly.
 __device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
@@ -115,6 +142,22 @@ __device__ __forceinline__ uint32_t vr_srgb_encode(float x, const float* thr)
         lo = ge ? mid : lo; hi = ge ? hi : mid - 1;
     }
     return (uint32_t)lo;
+}
+
+// Same result as vr_srgb_encode (the largest k with thr[k] <= x), found from a v_log/v_exp
+// estimate of the OETF and corrected against the thresholds: usually two LDS reads instead of
+// an 8-step binary search.  The estimate only has to be close; exactness comes from the fix-up.
+__device__ __forceinline__ uint32_t vr_srgb_encode_fast(float x, const float* thr)
+{
+    if (!(x >= 0.0f)) return 0u;
+    const float xc = vr_min(x, 1.0f);
+    const float y = xc <= 0.0031308f ? xc * 12.92f
+                                     : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xc) * (1.0f / 2.4f)) - 0.055f;
+    int g = (int)(y * 255.0f + 0.5f);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    while (g > 0 && x < thr[g]) g--;
+    while (g < 255 && x >= thr[g + 1]) g++;
+    return (uint32_t)g;
 }
 
 __device__ __forceinline__ uint32_t vr_snorm16(float v)
