@@ -53,6 +53,24 @@ struct RasterArgs {
 enum { C_COUNT = 0, C_FLAGS = 1, C_HARDTRIS = 2, C_XVERTS = 3, C_HARDLIST = 4, C_BINTOTAL = 5 };
 
 
+// One bilinear tap through the quad (footprint) table, split into address and filter so that the
+// loads of all taps of a pixel can be issued back to back before the first one is consumed.
+struct QuadTap { uint32_t idx; float fx, fy; };
+__device__ __forceinline__ QuadTap quad_tap(int w, int h, float u, float v)
+{
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    QuadTap q; q.fx = x - xf; q.fy = y - yf;
+    xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
+    q.idx = (uint32_t)(((int)yf + 1) * (w + 2) + ((int)xf + 1));
+    return q;
+}
+__device__ __forceinline__ float quad_filter(uint32_t e, const QuadTap& q, const float* __restrict__ r8)
+{
+    const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
+    const float top = t00 + (t10 - t00) * q.fx, bot = t01 + (t11 - t01) * q.fx;
+    return top + (bot - top) * q.fy;
+}
 // ---------------------------------------------------------------------------------------
 // vertex stage (terrain_vs.hlsl:35-62)
 // ---------------------------------------------------------------------------------------
@@ -74,7 +92,9 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
                                                  const uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
 {
     __shared__ float r8[256];
+    __shared__ uint32_t s_qoff[kMaxLevels];
     r8[threadIdx.x] = (float)threadIdx.x / 255.0f;     // UNORM8 -> float, correctly rounded
+    if (threadIdx.x < kMaxLevels) s_qoff[threadIdx.x] = hm.qoff[threadIdx.x];
     __syncthreads();
     const uint32_t total = counters[C_COUNT] * (uint32_t)kVertsPerInst;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
@@ -107,7 +127,16 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
         // sampleHeight (:27-33)
         const float halfSize = a.world_size * 0.5f;
         const float u = (world[0] + halfSize) / a.world_size, w_ = (world[2] + halfSize) / a.world_size;
-        world[1] = vr_trilinear_r8q(hm, 0.1f, u, w_, r8) * a.max_height;                                  // :51
+        {   // SampleLevel(linearClamp, uv, 0.1): levels 0 and 1 fetched together
+            const LodSplit ls = vr_lod_split(hm.levels, 0.1f);
+            const int l1 = min(ls.l0 + 1, hm.levels - 1);
+            const int w0 = max(1, hm.w0 >> ls.l0), h0 = max(1, hm.h0 >> ls.l0), w1 = max(1, hm.w0 >> l1), h1 = max(1, hm.h0 >> l1);
+            const QuadTap t0 = quad_tap(w0, h0, u, w_), t1 = quad_tap(w1, h1, u, w_);
+            const uint32_t e0 = hm.quad[s_qoff[ls.l0] + t0.idx], e1 = hm.quad[s_qoff[l1] + t1.idx];
+            const float s0 = quad_filter(e0, t0, r8), s1 = quad_filter(e1, t1, r8);
+            const float hv = ls.f > 0.0f ? s0 + (s1 - s0) * ls.f : s0;
+            world[1] = hv * a.max_height;                                                           // :51
+        }
         float viewPos[4], clip[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) viewPos[j] = ((world[0] * a.w2v[0 * 4 + j] + world[1] * a.w2v[1 * 4 + j]) + world[2] * a.w2v[2 * 4 + j]) + world[3] * a.w2v[3 * 4 + j];   // :60
@@ -479,25 +508,70 @@ __device__ __forceinline__ float div_ws(const RasterArgs& a, float s)
 }
 __device__ __forceinline__ float to_uv(const RasterArgs& a, float x) { return div_ws(a, x + a.world_size * 0.5f); }
 
-// main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels
+__device__ __forceinline__ void srgb_filter(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11, const BilinearSetup& s,
+                                            const float* __restrict__ lut, float out[3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t00 = lut[(p00 >> (8 * c)) & 255u], t10 = lut[(p10 >> (8 * c)) & 255u];
+        const float t01 = lut[(p01 >> (8 * c)) & 255u], t11 = lut[(p11 >> (8 * c)) & 255u];
+        const float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
+        out[c] = top + (bot - top) * s.fy;
+    }
+}
+
+// main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels.  qoff / aoff: LDS copies of the
+// per-level offset tables (no dependent global load in front of a texel fetch).  The finer level of
+// the four height taps and of the albedo tap is fetched as one batch of 8 loads; the coarser level
+// (only when a LOD fraction is non-zero) as a second batch.
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
-                                             const float* __restrict__ thr, const float* __restrict__ r8, const Attr& p,
+                                             const float* __restrict__ thr, const float* __restrict__ r8,
+                                             const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
     const float u = to_uv(a, p.wx), v = to_uv(a, p.wz);                                      // :12-13, :20-21
     const float dudx = div_ws(a, p.dwxdx), dvdx = div_ws(a, p.dwzdx), dudy = div_ws(a, p.dwxdy), dvdy = div_ws(a, p.dwzdy);
     const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
     const float lod_c = (hm.w0 == al.w0 && hm.h0 == al.h0) ? lod_h : vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
+    const LodSplit lh = vr_lod_split(hm.levels, lod_h), lc = vr_lod_split(al.levels, lod_c);
     const float offset = 0.1f;                                                              // :59
-    const float hDx = vr_trilinear_r8q(hm, lod_h, u + offset, v + 0.0f, r8) - vr_trilinear_r8q(hm, lod_h, u + (-offset), v + 0.0f, r8);   // :60
-    const float hDy = vr_trilinear_r8q(hm, lod_h, u + 0.0f, v + offset, r8) - vr_trilinear_r8q(hm, lod_h, u + 0.0f, v + (-offset), r8);   // :61
+    const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset), u0 = u + 0.0f, v0 = v + 0.0f;
+    float hgt[4], col[3];
+    {
+        const int w = max(1, hm.w0 >> lh.l0), h = max(1, hm.h0 >> lh.l0), wc = max(1, al.w0 >> lc.l0), hc = max(1, al.h0 >> lc.l0);
+        const uint32_t* q = hm.quad + qoff[lh.l0];
+        const uint32_t* c = (const uint32_t*)(al.base + aoff[lc.l0]);
+        const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
+        const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
+        const uint32_t e0 = q[t0.idx], e1 = q[t1.idx], e2 = q[t2.idx], e3 = q[t3.idx];
+        const uint32_t p00 = c[s.i00], p10 = c[s.i10], p01 = c[s.i01], p11 = c[s.i11];
+        hgt[0] = quad_filter(e0, t0, r8); hgt[1] = quad_filter(e1, t1, r8); hgt[2] = quad_filter(e2, t2, r8); hgt[3] = quad_filter(e3, t3, r8);
+        srgb_filter(p00, p10, p01, p11, s, lut, col);
+    }
+    if (lh.f > 0.0f || lc.f > 0.0f) {
+        // blending with a zero fraction returns the finer sample exactly, so one branch serves both textures
+        const int l1h = min(lh.l0 + 1, hm.levels - 1), l1c = min(lc.l0 + 1, al.levels - 1);
+        const int w = max(1, hm.w0 >> l1h), h = max(1, hm.h0 >> l1h), wc = max(1, al.w0 >> l1c), hc = max(1, al.h0 >> l1c);
+        const uint32_t* q = hm.quad + qoff[l1h];
+        const uint32_t* c = (const uint32_t*)(al.base + aoff[l1c]);
+        const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
+        const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
+        const uint32_t e0 = q[t0.idx], e1 = q[t1.idx], e2 = q[t2.idx], e3 = q[t3.idx];
+        const uint32_t p00 = c[s.i00], p10 = c[s.i10], p01 = c[s.i01], p11 = c[s.i11];
+        const float g0 = quad_filter(e0, t0, r8), g1 = quad_filter(e1, t1, r8), g2 = quad_filter(e2, t2, r8), g3 = quad_filter(e3, t3, r8);
+        float cb[3];
+        srgb_filter(p00, p10, p01, p11, s, lut, cb);
+        hgt[0] = hgt[0] + (g0 - hgt[0]) * lh.f; hgt[1] = hgt[1] + (g1 - hgt[1]) * lh.f;
+        hgt[2] = hgt[2] + (g2 - hgt[2]) * lh.f; hgt[3] = hgt[3] + (g3 - hgt[3]) * lh.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) col[k] = col[k] + (cb[k] - col[k]) * lc.f;
+    }
+    const float hDx = hgt[0] - hgt[1], hDy = hgt[2] - hgt[3];                                // :60-61
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
     const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
     nx *= inv; ny *= inv; nz *= inv;
-    float col[3];
-    vr_trilinear_srgb(al, lod_c, u, v, lut, col);                                           // :68
     diffuse = vr_srgb_encode_fast(col[0], thr) | (vr_srgb_encode_fast(col[1], thr) << 8) | (vr_srgb_encode_fast(col[2], thr) << 16)
-            | 0xff000000u;                                                                  // :73-75
+            | 0xff000000u;                                                                  // :68, :73-75
     n01 = vr_snorm16(nx) | (vr_snorm16(ny) << 16);                                          // :78
     n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
 }
@@ -569,7 +643,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __shared__ float lut[256];
     __shared__ float thr[256];
     __shared__ float r8[256];
+    __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * kRasterTile, oy = tyi * kRasterTile;
@@ -679,7 +755,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
             const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
             const Attr p = interp_attr(s0, s1, s2, t.inv_area, td, E1, E2);
-            pixel_shader(a, hm, al, lut, thr, r8, p, dif[k], nn0[k], nn1[k]);
+            pixel_shader(a, hm, al, lut, thr, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);
