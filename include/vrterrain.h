@@ -244,6 +244,9 @@ VR_API int vr_synth_heightmap(vr_context* ctx, int32_t size, uint32_t seed, uint
 VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
                            const uint8_t* height_r8, uint8_t* out_srgba8);
 
+/* test helper: the device's linear -> sRGB8 render-target conversion applied to n host floats */
+VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, size_t n, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

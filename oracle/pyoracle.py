@@ -68,6 +68,7 @@ def lib():
     L.orc_srgb8_to_linear.argtypes = [C.c_uint8]
     L.orc_linear_to_srgb8.restype = C.c_uint8
     L.orc_linear_to_srgb8.argtypes = [C.c_float]
+    L.orc_linear_to_srgb8_batch.argtypes = [vp, C.c_size_t, vp]
     L.orc_time_tree_build.restype = C.c_double
     L.orc_time_tree_build.argtypes = [P(TerrainParams), vp, C.c_int, C.c_int]
     L.orc_time_select.restype = C.c_double
@@ -203,6 +204,13 @@ def deferred(view, gb, lights, amb_top, amb_bottom, f32=False):
         fn = lib().orc_deferred
     fn(C.byref(view), gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular), _ptr(gb.normals),
        _ptr(gb.emissive), arr, n, _f3(amb_top), _f3(amb_bottom), _ptr(out))
+    return out
+
+
+def linear_to_srgb8(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    lib().orc_linear_to_srgb8_batch(_ptr(x), x.size, _ptr(out))
     return out
 
 

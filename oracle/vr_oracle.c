@@ -93,6 +93,10 @@ uint8_t orc_linear_to_srgb8(float x)
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= g_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
     return (uint8_t)lo;
 }
+void orc_linear_to_srgb8_batch(const float* in, size_t n, uint8_t* out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = orc_linear_to_srgb8(in[i]);
+}
 static inline uint8_t unorm8(float a)
 {
     if (!(a > 0.0f)) return 0;

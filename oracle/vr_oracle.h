@@ -92,6 +92,7 @@ float    orc_half_to_float(uint16_t h);
 uint16_t orc_float_to_half(float f);
 float    orc_srgb8_to_linear(uint8_t c);
 uint8_t  orc_linear_to_srgb8(float x);
+void     orc_linear_to_srgb8_batch(const float* in, size_t n, uint8_t* out);
 
 /* CPU baseline legs (bench.py cpu_baseline, kind "port"): the reference's CPU-side
  * terrain work, single-threaded like the reference's main thread. Return seconds. */

@@ -274,3 +274,30 @@ def test_tile_partition_emulated_on_one_gpu_equals_unsplit(scene256, oracle, gpu
     assert np.array_equal(got, ref)
     for o in (big, out, full, rt):
         o.close()
+
+
+def test_device_srgb_encode_equals_threshold_search(oracle, gpu_ctx):
+    """The render-target conversion used by the pixel shader (log/exp estimate + boundary re-check)
+    must equal the oracle's threshold search for every input: dense sweep, every threshold +-4 ulp,
+    random values, specials."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    # thresholds: smallest x that encodes to k, found by bisection on the oracle
+    lo = np.zeros(255, np.float32)
+    hi = np.ones(255, np.float32)
+    for _ in range(40):
+        mid = ((lo.astype(np.float64) + hi) / 2).astype(np.float32)
+        ge = oracle.linear_to_srgb8(mid) >= np.arange(1, 256)
+        hi = np.where(ge, mid, hi)
+        lo = np.where(ge, lo, mid)
+    near = np.concatenate([(hi.view(np.uint32).astype(np.int64) + d).astype(np.uint32).view(np.float32) for d in range(-4, 5)])
+    x = np.concatenate([
+        np.arange(0, 1 << 22, dtype=np.float32) / np.float32(1 << 22) * np.float32(1.05),
+        near, rng.random(1 << 20, dtype=np.float32), (rng.random(1 << 18, dtype=np.float32) * 0.01).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, 1.5, -1.0, np.inf, -np.inf, np.nan, 1e-30, 0.0031308, 0.00313081, 0.0031307], np.float32)])
+    got = np.empty(x.size, np.uint8)
+    vr.capi.check(gpu_ctx.lib.vr_debug_srgb_encode(gpu_ctx.handle, x.ctypes.data_as(C.c_void_p), x.size, got.ctypes.data_as(C.c_void_p)),
+                  "vr_debug_srgb_encode")
+    want = oracle.linear_to_srgb8(x)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:5], x[bad[:5]], got[bad[:5]], want[bad[:5]])

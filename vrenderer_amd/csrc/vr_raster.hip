@@ -62,7 +62,7 @@ __device__ __forceinline__ QuadTap quad_tap(int w, int h, float u, float v)
     float xf = floorf(x), yf = floorf(y);
     QuadTap q; q.fx = x - xf; q.fy = y - yf;
     xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
-    q.idx = (uint32_t)(((int)yf + 1) * (w + 2) + ((int)xf + 1));
+    q.idx = (uint32_t)(__mul24((int)yf + 1, w + 2) + ((int)xf + 1));
     return q;
 }
 __device__ __forceinline__ float quad_filter(uint32_t e, const QuadTap& q, const float* __restrict__ r8)

@@ -22,7 +22,8 @@ __device__ __forceinline__ BilinearSetup vr_bilinear_setup(int w, int h, float u
     int x0 = (int)xf, y0 = (int)yf;
     int x1 = vr_clampi(x0 + 1, 0, w - 1), y1 = vr_clampi(y0 + 1, 0, h - 1);
     x0 = vr_clampi(x0, 0, w - 1); y0 = vr_clampi(y0, 0, h - 1);
-    s.i00 = y0 * w + x0; s.i10 = y0 * w + x1; s.i01 = y1 * w + x0; s.i11 = y1 * w + x1;
+    const int r0 = __mul24(y0, w), r1 = __mul24(y1, w);
+    s.i00 = r0 + x0; s.i10 = r0 + x1; s.i01 = r1 + x0; s.i11 = r1 + x1;
     return s;
 }
 
@@ -144,19 +145,26 @@ __device__ __forceinline__ uint32_t vr_srgb_encode(float x, const float* thr)
     return (uint32_t)lo;
 }
 
-// Same result as vr_srgb_encode (the largest k with thr[k] <= x), found from a v_log/v_exp
-// estimate of the OETF and corrected against the thresholds: usually two LDS reads instead of
-// an 8-step binary search.  The estimate only has to be close; exactness comes from the fix-up.
+// Same result as vr_srgb_encode (the largest k with thr[k] <= x).  The OETF is estimated with
+// v_log/v_exp; thr[k] is the float nearest to EOTF((k - 0.5) / 255), so k = floor(OETF(x)*255 + 0.5)
+// whenever that value is not within rounding distance of an integer.  The estimate is good to
+// ~1e-5 codes (1-ulp log2/exp2, thresholds rounded to float), so only values whose fractional part
+// is within 1/64 of a code boundary (about 3 %) are re-checked against the LDS thresholds.
 __device__ __forceinline__ uint32_t vr_srgb_encode_fast(float x, const float* thr)
 {
     if (!(x >= 0.0f)) return 0u;
     const float xc = vr_min(x, 1.0f);
     const float y = xc <= 0.0031308f ? xc * 12.92f
                                      : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xc) * (1.0f / 2.4f)) - 0.055f;
-    int g = (int)(y * 255.0f + 0.5f);
+    const float yy = y * 255.0f + 0.5f;
+    const float fl = floorf(yy);
+    int g = (int)fl;
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
-    while (g > 0 && x < thr[g]) g--;
-    while (g < 255 && x >= thr[g + 1]) g++;
+    const float fr = yy - fl;
+    if (fr < (1.0f / 64.0f) || fr > (63.0f / 64.0f)) {
+        while (g > 0 && x < thr[g]) g--;
+        while (g < 255 && x >= thr[g + 1]) g++;
+    }
     return (uint32_t)g;
 }
 
