@@ -41,6 +41,18 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
     VR_HIP(hipMalloc(&c->d_srgb_thr, 256 * sizeof(float)));
     VR_HIP(hipMemcpy(c->d_srgb_lut, c->h_srgb_lut, 256 * sizeof(float), hipMemcpyHostToDevice));
     VR_HIP(hipMemcpy(c->d_srgb_thr, c->h_srgb_thr, 256 * sizeof(float), hipMemcpyHostToDevice));
+    {   // start table for the device encoder: code of the smallest float in each bucket
+        uint8_t tab[kEncTabSize];
+        for (int b = 0; b < kEncTabSize; b++) {
+            const uint32_t bits = (uint32_t)(b + kEncTabBase) << 16;
+            float x; memcpy(&x, &bits, 4);
+            int lo = 0, hi = 255;
+            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
+            tab[b] = (uint8_t)lo;
+        }
+        VR_HIP(hipMalloc(&c->d_enc_tab, kEncTabSize));
+        VR_HIP(hipMemcpy(c->d_enc_tab, tab, kEncTabSize, hipMemcpyHostToDevice));
+    }
     *out = c;
     return VR_OK;
 }
@@ -49,7 +61,7 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr);
+    (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); (void)hipFree(c->d_enc_tab);
     (void)hipFree(c->d_owned_tiles); (void)hipFree(c->d_tile_slot); (void)hipFree(c->d_raster_tiles);
     timing_reset(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -31,6 +31,9 @@ constexpr int kRasterTile = 64;              // raster/bin tile (pixels)
 constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
 constexpr int kMaxLevels = 16;
 constexpr float kGuardBand = 100.0f;
+// linear -> sRGB8 start table: one bucket per (exponent, top 7 mantissa bits) from 2^-13 to 1.0
+constexpr int kEncTabBase = (127 - 13) << 7;
+constexpr int kEncTabSize = (13 << 7) + 1;
 
 // Mip chain in device memory, passed to kernels by value.
 struct DevTex {
@@ -77,6 +80,7 @@ struct vr_context {
     float* d_srgb_thr = nullptr;   // 256 floats: encode thresholds
     float h_srgb_lut[256];
     float h_srgb_thr[256];
+    uint8_t* d_enc_tab = nullptr;  // kEncTabSize bytes: sRGB8 code of the smallest float of each bucket
     // cached partition tables (device), rebuilt when (w,h,rank,world) changes
     int part_w = 0, part_h = 0, part_rank = -1, part_world = 0;
     int32_t* d_owned_tiles = nullptr;   // owner-tile ids (128x128) owned by this rank

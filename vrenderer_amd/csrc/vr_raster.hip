@@ -525,7 +525,7 @@ __device__ __forceinline__ void srgb_filter(uint32_t p00, uint32_t p10, uint32_t
 // the four height taps and of the albedo tap is fetched as one batch of 8 loads; the coarser level
 // (only when a LOD fraction is non-zero) as a second batch.
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
-                                             const float* __restrict__ thr, const float* __restrict__ r8,
+                                             const float* __restrict__ thr, const uint8_t* __restrict__ enc, const float* __restrict__ r8,
                                              const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
@@ -570,7 +570,7 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
     const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
     nx *= inv; ny *= inv; nz *= inv;
-    diffuse = vr_srgb_encode_fast(col[0], thr) | (vr_srgb_encode_fast(col[1], thr) << 8) | (vr_srgb_encode_fast(col[2], thr) << 16)
+    diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
     n01 = vr_snorm16(nx) | (vr_snorm16(ny) << 16);                                          // :78
     n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
@@ -637,15 +637,18 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                                                  const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
-                                                 const float* __restrict__ lut_g, const float* __restrict__ thr_g, uint32_t spec_const)
+                                                 const float* __restrict__ lut_g, const float* __restrict__ thr_g,
+                                                 const uint8_t* __restrict__ enc_g, uint32_t spec_const)
 {
     __shared__ unsigned long long vis[kRasterTile * kRasterTile];
+    __shared__ uint8_t enc[kEncTabSize + 3];
     __shared__ float lut[256];
     __shared__ float thr[256];
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
+    for (int i = tid; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * kRasterTile, oy = tyi * kRasterTile;
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
             const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
             const Attr p = interp_attr(s0, s1, s2, t.inv_area, td, E1, E2);
-            pixel_shader(a, hm, al, lut, thr, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
+            pixel_shader(a, hm, al, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);
@@ -879,7 +882,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         VrKernelScope ks(ctx, VR_K_RASTER);
         hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, t->d_verts, hard_tris, t->d_hard_first,
                            t->d_tile_count, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, spec_const);
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;

@@ -198,13 +198,16 @@ extern "C" VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t se
 }
 
 // ---- test helper ---------------------------------------------------------------------------
-__global__ void k_debug_srgb_encode(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out, const float* __restrict__ thr_g)
+__global__ void k_debug_srgb_encode(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out, const float* __restrict__ thr_g,
+                                    const uint8_t* __restrict__ tab_g)
 {
     __shared__ float thr[256];
+    __shared__ uint8_t tab[kEncTabSize];
     thr[threadIdx.x] = thr_g[threadIdx.x];
+    for (int i = threadIdx.x; i < kEncTabSize; i += blockDim.x) tab[i] = tab_g[i];
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (uint8_t)vr_srgb_encode_fast(in[i], thr);
+        out[i] = (uint8_t)vr_srgb_encode_fast(in[i], thr, tab);
 }
 extern "C" VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, size_t n, uint8_t* out)
 {
@@ -215,7 +218,7 @@ extern "C" VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, siz
     hipError_t e = hipMalloc(&dout, n);
     if (e != hipSuccess) { (void)hipFree(din); VR_HIP(e); }
     e = hipMemcpyAsync(din, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    hipLaunchKernelGGL(k_debug_srgb_encode, dim3(2048), dim3(256), 0, ctx->stream, din, n, dout, ctx->d_srgb_thr);
+    hipLaunchKernelGGL(k_debug_srgb_encode, dim3(2048), dim3(256), 0, ctx->stream, din, n, dout, ctx->d_srgb_thr, ctx->d_enc_tab);
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(din); (void)hipFree(dout);

@@ -145,27 +145,18 @@ __device__ __forceinline__ uint32_t vr_srgb_encode(float x, const float* thr)
     return (uint32_t)lo;
 }
 
-// Same result as vr_srgb_encode (the largest k with thr[k] <= x).  The OETF is estimated with
-// v_log/v_exp; thr[k] is the float nearest to EOTF((k - 0.5) / 255), so k = floor(OETF(x)*255 + 0.5)
-// whenever that value is not within rounding distance of an integer.  The estimate is good to
-// ~1e-5 codes (1-ulp log2/exp2, thresholds rounded to float), so only values whose fractional part
-// is within 1/64 of a code boundary (about 3 %) are re-checked against the LDS thresholds.
-__device__ __forceinline__ uint32_t vr_srgb_encode_fast(float x, const float* thr)
+// Same result as vr_srgb_encode (the largest k with thr[k] <= x) without the 8-step search: the
+// float's exponent and top 7 mantissa bits select a bucket whose smallest value has code tab[b]
+// (host-built from the same thresholds); a bucket spans at most ~0.6 codes, so one comparison
+// against the next threshold (a loop, for safety) finishes it.  tab / thr live in LDS.
+__device__ __forceinline__ uint32_t vr_srgb_encode_fast(float x, const float* __restrict__ thr, const uint8_t* __restrict__ tab)
 {
-    if (!(x >= 0.0f)) return 0u;
-    const float xc = vr_min(x, 1.0f);
-    const float y = xc <= 0.0031308f ? xc * 12.92f
-                                     : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xc) * (1.0f / 2.4f)) - 0.055f;
-    const float yy = y * 255.0f + 0.5f;
-    const float fl = floorf(yy);
-    int g = (int)fl;
-    g = g < 0 ? 0 : (g > 255 ? 255 : g);
-    const float fr = yy - fl;
-    if (fr < (1.0f / 64.0f) || fr > (63.0f / 64.0f)) {
-        while (g > 0 && x < thr[g]) g--;
-        while (g < 255 && x >= thr[g + 1]) g++;
-    }
-    return (uint32_t)g;
+    if (!(x > 0.0f)) return 0u;                                    // zero (either sign), negatives and NaN
+    int b = (int)(__float_as_uint(x) >> 16) - kEncTabBase;
+    b = b < 0 ? 0 : (b > kEncTabSize - 1 ? kEncTabSize - 1 : b);   // below 2^-13 -> code 0, >= 1 -> 255
+    uint32_t g = tab[b];
+    while (g < 255u && x >= thr[g + 1u]) g++;
+    return g;
 }
 
 __device__ __forceinline__ uint32_t vr_snorm16(float v)
