@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--size", type=int, default=2048, help="heightmap / world size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
+    ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, packed tiles, all-gather, de-tile) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,17 +99,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-    if args.gpus == 1:
+    if args.gpus == 1 and not args.force_dist:
         world, rank, local_rank = 1, 0, 0
+    use_dist = world > 1 or args.force_dist
 
     import numpy as np
     torch = None
     dist = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import vrenderer_amd as vr
     from vrenderer_amd.passes import frame_detile, partition_info
@@ -126,7 +132,7 @@ def main():
     rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
 
     part = None
-    if world > 1:
+    if use_dist:
         part = vr.Partition(rank, world)
         info = partition_info(W, H, rank, world)
         packed = torch.empty(info["packed_bytes"] // 2, dtype=torch.float16, device="cuda")
@@ -149,12 +155,12 @@ def main():
         v = views[i % 120]
         tp.Render(v, v, rt, rp, part)
         deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, part)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, packed)
             frame_detile(ctx, gathered.data_ptr(), world, frame)
 
     def sync():
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -174,7 +180,19 @@ def main():
     ctx.timing_enable(False)
     n_nodes = tp.num_chunks()
 
-    if world > 1:
+    verified = None
+    if args.verify:
+        last = views[(args.warmup + args.steps - 1) % 120]
+        got = frame.download()
+        ref_img = vr.HdrImage(ctx, W, H)
+        tp.Render(last, last, rt, rp, None)
+        deferred.Render(last, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, ref_img, None)
+        verified = bool(np.array_equal(got, ref_img.download()))
+        ref_img.close()
+        if not verified:
+            raise SystemExit(f"rank {rank}: assembled frame differs from the unsplit frame")
+
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -205,7 +223,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
-                                   + ("+all-gather+detile" if world > 1 else ""),
+                                   + ("+all-gather+detile" if use_dist else ""),
                        "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,
                        "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"},
             # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
@@ -215,6 +233,8 @@ def main():
             "kernels": kern,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
         }
+        if verified is not None:
+            out["frame_verified_against_unsplit"] = verified
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)
@@ -222,7 +242,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -149,7 +149,7 @@ VR_API const char* vr_version(void);
  * the reference's PROFILE_GPU_SCOPE timestamp queries (Profiler.h:55-125,
  * Renderer.cpp:326-437).  Kernel ids: */
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
-       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_COUNT };
+       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_COUNT };
 VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
 /* Synchronises the stream; per kernel id: summed milliseconds and launch count since
  * the last enable/collect; resets the samples. */
@@ -226,6 +226,14 @@ VR_API int  vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* 
                               const vr_light* lights, int32_t num_lights,
                               const float ambient_top[3], const float ambient_bottom[3],
                               vr_image* hdr_out, const vr_partition* part);
+
+/* The same pass for many lights (BASELINE config 5: 1024 point lights): per 16x16 screen tile the
+ * lights are culled against the tile's world-space bounds into an LDS list, then every pixel
+ * shades only that list.  Same inputs/outputs as vr_deferred_light; any number of lights. */
+VR_API int  vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb,
+                                    const vr_light* lights, int32_t num_lights,
+                                    const float ambient_top[3], const float ambient_bottom[3],
+                                    vr_image* hdr_out, const vr_partition* part);
 
 /* ---- multi-GPU frame assembly (new) -------------------------------- */
 VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_partition* part,

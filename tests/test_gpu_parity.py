@@ -301,3 +301,58 @@ def test_device_srgb_encode_equals_threshold_search(oracle, gpu_ctx):
     want = oracle.linear_to_srgb8(x)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (bad[:5], x[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
+def _scene_lights(scene, n):
+    lights = [vr.reference_sun()] + vr.synthetic_point_lights(n - 1, float(scene["size"]), scene["h"], 400.0, seed=9001)
+    for l in lights[1:]:                      # ranges authored for the 2048 world; scale to this scene
+        l.angular_size_or_inv_range *= 2048.0 / scene["size"]
+    return lights
+
+
+def test_tiled_deferred_1024_lights_matches_oracle(scene256, oracle, gpu_ctx):
+    """BASELINE config 5 in small: 1 sun + 1023 point lights; the culled per-tile sum must equal the
+    oracle's all-lights loop (stated tolerance: per-channel RMS <= 1e-4)."""
+    w, h = 256, 144
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v, gb_o, planes, _, _ = _render_both(scene256, oracle, gpu_ctx, eye, tgt, w, h)
+    lights = _scene_lights(scene256, 1024)
+    ref32 = oracle.deferred(v, gb_o, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    lit = oracle.deferred(v, gb_o, lights[:1], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    assert np.abs(ref32 - lit).max() > 1e-3, "the point lights must contribute for the test to mean anything"
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    for k, arr in (("depth", gb_o.depth), ("diffuse", gb_o.diffuse), ("specular", gb_o.specular),
+                   ("normals", gb_o.normals), ("emissive", gb_o.emissive)):
+        rt.upload(k, arr)
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    for c in range(3):
+        rms = float(np.sqrt(np.mean((got[..., c] - ref32[..., c]) ** 2)))
+        assert rms <= 1e-4, (c, rms)
+    assert np.abs(got[..., :3] - ref32[..., :3]).max() <= 2e-3 * max(1.0, float(ref32.max()))
+    # the 16-light streaming kernel and the tiled kernel agree on a 16-light list
+    hdr2 = vr.HdrImage(gpu_ctx, w, h)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, lights[:16], AMBIENT_TOP, AMBIENT_BOTTOM, hdr2)
+    vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights[:16], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    a16 = oracle.half_to_float(hdr.download()).astype(np.float64)
+    b16 = oracle.half_to_float(hdr2.download()).astype(np.float64)
+    assert np.sqrt(np.mean((a16 - b16) ** 2)) <= 1e-5
+    # partitioned (packed) output of the tiled kernel
+    from vrenderer_amd.passes import frame_detile, partition_info
+    world = 2
+    info = partition_info(w, h, 0, world)
+    gathered = np.zeros(world * info["packed_bytes"] // 2, np.uint16)
+    vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    full = hdr.download()
+    for r in range(world):
+        packed = vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+        vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, packed, vr.Partition(r, world))
+        gathered[r * info["packed_bytes"] // 2:(r + 1) * info["packed_bytes"] // 2] = packed.download(info["packed_bytes"])
+        packed.close()
+    big = vr.HdrImage(gpu_ctx, 128, world * info["max_owned"] * 128)
+    big.upload(gathered)
+    frame_detile(gpu_ctx, big.device_ptr, world, hdr2)
+    assert np.array_equal(hdr2.download(), full)
+    for o in (big, hdr, hdr2, rt):
+        o.close()

@@ -20,7 +20,7 @@ VR_ERR_HIP = 6
 VR_LIGHT_DIRECTIONAL = 1
 VR_LIGHT_SPOT = 2
 VR_LIGHT_POINT = 3
-VR_K_COUNT = 10
+VR_K_COUNT = 11
 
 
 class TerrainParams(C.Structure):
@@ -113,7 +113,7 @@ EXPORTS = [
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_select", "vr_terrain_render", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
-    "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_partition_num_tiles",
+    "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode",
 ]
 
@@ -177,6 +177,8 @@ def load_library():
         "vr_image_upload": (C.c_int, [vp, vp, C.c_size_t]),
         "vr_deferred_light": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
                                         vp, P(Partition)]),
+        "vr_deferred_light_tiled": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
+                                              vp, P(Partition)]),
         "vr_partition_num_tiles": (C.c_int, [C.c_int32, C.c_int32, P(Partition), P(C.c_int32), P(C.c_int32),
                                              P(C.c_int32), P(C.c_int32)]),
         "vr_partition_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -46,99 +46,129 @@ __device__ __forceinline__ float dot3c(float ax, float ay, float az, float bx, f
     return ax * bx + ay * by + az * bz;
 }
 
-__device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
-                                            uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
-                                            float out[3])
+// Everything of a pixel that does not depend on the light.
+struct Surface {
+    float albedo[3], F0[3], E[3], N[3], wp[3], vi[3], R[3];
+    float occlusion, alpha, a2, kk, gv;
+};
+
+__device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
+                                                  uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23)
 {
 #pragma clang fp contract(fast)
-    const float albedo[3] = { lut[diff & 255u], lut[(diff >> 8) & 255u], lut[(diff >> 16) & 255u] };
-    const float F0[3] = { lut[spec & 255u], lut[(spec >> 8) & 255u], lut[(spec >> 16) & 255u] };
-    const float occlusion = (float)(spec >> 24) * (1.0f / 255.0f);
+    Surface s;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { s.albedo[c] = lut[(diff >> (8 * c)) & 255u]; s.F0[c] = lut[(spec >> (8 * c)) & 255u]; }
+    s.occlusion = (float)(spec >> 24) * (1.0f / 255.0f);
     const float sn16 = 1.0f / 32767.0f;
-    const float N[3] = { vr_max((float)(int16_t)(n01 & 0xffffu) * sn16, -1.0f), vr_max((float)(int16_t)(n01 >> 16) * sn16, -1.0f),
-                         vr_max((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f) };
+    s.N[0] = vr_max((float)(int16_t)(n01 & 0xffffu) * sn16, -1.0f); s.N[1] = vr_max((float)(int16_t)(n01 >> 16) * sn16, -1.0f);
+    s.N[2] = vr_max((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f);
     const float rough = vr_max((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
-    const float E[3] = { vr_half_to_float(e01 & 0xffffu), vr_half_to_float(e01 >> 16), vr_half_to_float(e23 & 0xffffu) };
-
+    s.E[0] = vr_half_to_float(e01 & 0xffffu); s.E[1] = vr_half_to_float(e01 >> 16); s.E[2] = vr_half_to_float(e23 & 0xffffu);
     // ReconstructWorldPosition: window -> clip -> world
     const float cx = ((float)px + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
     float wp4[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
     const float rw = fast_rcp(wp4[3]);
-    const float wp[3] = { wp4[0] * rw, wp4[1] * rw, wp4[2] * rw };
-    const float d[3] = { wp[0] - a.cam[0], wp[1] - a.cam[1], wp[2] - a.cam[2] };
+    s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
+    const float d[3] = { s.wp[0] - a.cam[0], s.wp[1] - a.cam[1], s.wp[2] - a.cam[2] };
     const float dl = fast_rsq(dot3c(d[0], d[1], d[2], d[0], d[1], d[2]));
-    const float vi[3] = { d[0] * dl, d[1] * dl, d[2] * dl };            // viewIncident; V = -vi
-    const float NdotVi = dot3c(vi[0], vi[1], vi[2], N[0], N[1], N[2]);
+    s.vi[0] = d[0] * dl; s.vi[1] = d[1] * dl; s.vi[2] = d[2] * dl;      // viewIncident; V = -vi
+    const float NdotVi = dot3c(s.vi[0], s.vi[1], s.vi[2], s.N[0], s.N[1], s.N[2]);
     const float two = 2.0f * NdotVi;
-    const float R[3] = { vi[0] - N[0] * two, vi[1] - N[1] * two, vi[2] - N[2] * two };   // reflect(viewIncident, N)
-    const float NdotV = vr_saturate(-NdotVi);
-    const float alpha = vr_max(0.01f, rough * rough);
-    const float a2 = alpha * alpha;
-    const float kk = ((rough + 1.0f) * (rough + 1.0f)) * 0.125f;
-    const float gv = NdotV * (1.0f - kk) + kk;
-    float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
-
-    for (int i = 0; i < a.num_lights; i++) {
-        const DevLight& Lc = a.lights[i];
-        float L[3], irr;                                                  // L = -incidentVector
-        if (Lc.type == VR_LIGHT_DIRECTIONAL) {
-            L[0] = -Lc.dir[0]; L[1] = -Lc.dir[1]; L[2] = -Lc.dir[2];
-            irr = Lc.intensity;
-        } else {
-            const float stl[3] = { Lc.pos[0] - wp[0], Lc.pos[1] - wp[1], Lc.pos[2] - wp[2] };
-            const float d2 = dot3c(stl[0], stl[1], stl[2], stl[0], stl[1], stl[2]);
-            const float rd = fast_rsq(d2);
-            L[0] = stl[0] * rd; L[1] = stl[1] * rd; L[2] = stl[2] * rd;
-            float att = 1.0f;
-            if (Lc.inv_range > 0.0f) {
-                const float q2 = d2 * (Lc.inv_range * Lc.inv_range);
-                const float s = vr_saturate(1.0f - q2 * q2);
-                att = s * s;
-                if (att == 0.0f) continue;
-            }
-            irr = (Lc.intensity * (rd * rd)) * att;
-        }
-        const float NdotLd = vr_max(dot3c(N[0], N[1], N[2], L[0], L[1], L[2]), 0.0f);
-        const float kd = (NdotLd * VR_INV_PI) * irr;
-        // area-light correction of L towards R (closed form of Donut's slerp)
-        const float cosT = vr_min(vr_max(dot3c(R[0], R[1], R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
-        float k1 = 0.0f, k2 = 1.0f;                                       // cosT >= cosH: CL = R
-        if (cosT < Lc.cosH) {
-            k2 = Lc.sinH * fast_rsq(vr_max(1.0f - cosT * cosT, 1e-12f));
-            k1 = Lc.cosH - cosT * k2;
-        }
-        const float CL[3] = { L[0] * k1 + R[0] * k2, L[1] * k1 + R[1] * k2, L[2] * k1 + R[2] * k2 };
-        float Hv[3] = { CL[0] - vi[0], CL[1] - vi[1], CL[2] - vi[2] };
-        const float hl2 = dot3c(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
-        const float hs = hl2 > 0.0f ? fast_rsq(hl2) : 0.0f;
-        const float NdotH = vr_saturate(dot3c(N[0], N[1], N[2], Hv[0], Hv[1], Hv[2]) * hs);
-        const float NdotL = vr_saturate(dot3c(N[0], N[1], N[2], CL[0], CL[1], CL[2]));
-        const float VdotH = vr_saturate(-dot3c(vi[0], vi[1], vi[2], Hv[0], Hv[1], Hv[2]) * hs);
-        const float corrAlpha = vr_saturate(alpha + 0.5f * Lc.tanH);
-        const float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
-        const float gl = NdotL * (1.0f - kk) + kk;
-        // D * G * NdotL / 4 * irradiance with D = a2/(pi dd^2) (alpha/corrAlpha)^2, G = 1/(gl gv)
-        const float num = (a2 * a2) * (NdotL * irr) * (0.25f * VR_INV_PI);
-        const float den = ((corrAlpha * dd) * (corrAlpha * dd)) * (gl * gv);
-        const float ks = num * fast_rcp(den);
-        const float om = 1.0f - VdotH;
-        const float om2 = om * om;
-        const float fw = (om2 * om2) * om;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float F = F0[c] + (1.0f - F0[c]) * fw;
-            diffuseTerm[c] += (albedo[c] * kd) * Lc.color[c];
-            specularTerm[c] += (F * ks) * Lc.color[c];
+    for (int c = 0; c < 3; c++) s.R[c] = s.vi[c] - s.N[c] * two;        // reflect(viewIncident, N)
+    const float NdotV = vr_saturate(-NdotVi);
+    s.alpha = vr_max(0.01f, rough * rough);
+    s.a2 = s.alpha * s.alpha;
+    s.kk = ((rough + 1.0f) * (rough + 1.0f)) * 0.125f;
+    s.gv = NdotV * (1.0f - s.kk) + s.kk;
+    return s;
+}
+
+// One light's contribution (ShadeSurface + GGX_AnalyticalLights_times_NdotL).  type/vec/inv_range etc.
+// are the DevLight fields; passed separately so that they may come from SGPRs or from LDS.
+__device__ __forceinline__ void add_light(const Surface& s, int type, const float vec[3], float inv_range, const float color[3],
+                                          float intensity, float cosH, float sinH, float tanH, float diffuseTerm[3], float specularTerm[3])
+{
+#pragma clang fp contract(fast)
+    float L[3], irr;                                                  // L = -incidentVector
+    if (type == VR_LIGHT_DIRECTIONAL) {
+        L[0] = -vec[0]; L[1] = -vec[1]; L[2] = -vec[2];
+        irr = intensity;
+    } else {
+        const float stl[3] = { vec[0] - s.wp[0], vec[1] - s.wp[1], vec[2] - s.wp[2] };
+        const float d2 = dot3c(stl[0], stl[1], stl[2], stl[0], stl[1], stl[2]);
+        const float rd = fast_rsq(d2);
+        L[0] = stl[0] * rd; L[1] = stl[1] * rd; L[2] = stl[2] * rd;
+        float att = 1.0f;
+        if (inv_range > 0.0f) {
+            const float q2 = d2 * (inv_range * inv_range);
+            const float sa = vr_saturate(1.0f - q2 * q2);
+            att = sa * sa;
+            if (att == 0.0f) return;
         }
+        irr = (intensity * (rd * rd)) * att;
     }
-    const float tt = N[1] * 0.5f + 0.5f;
+    const float NdotLd = vr_max(dot3c(s.N[0], s.N[1], s.N[2], L[0], L[1], L[2]), 0.0f);
+    const float kd = (NdotLd * VR_INV_PI) * irr;
+    // area-light correction of L towards R (closed form of Donut's slerp)
+    const float cosT = vr_min(vr_max(dot3c(s.R[0], s.R[1], s.R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
+    float k1 = 0.0f, k2 = 1.0f;                                       // cosT >= cosH: CL = R
+    if (cosT < cosH) {
+        k2 = sinH * fast_rsq(vr_max(1.0f - cosT * cosT, 1e-12f));
+        k1 = cosH - cosT * k2;
+    }
+    const float CL[3] = { L[0] * k1 + s.R[0] * k2, L[1] * k1 + s.R[1] * k2, L[2] * k1 + s.R[2] * k2 };
+    const float Hv[3] = { CL[0] - s.vi[0], CL[1] - s.vi[1], CL[2] - s.vi[2] };
+    const float hl2 = dot3c(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
+    const float hs = hl2 > 0.0f ? fast_rsq(hl2) : 0.0f;
+    const float NdotH = vr_saturate(dot3c(s.N[0], s.N[1], s.N[2], Hv[0], Hv[1], Hv[2]) * hs);
+    const float NdotL = vr_saturate(dot3c(s.N[0], s.N[1], s.N[2], CL[0], CL[1], CL[2]));
+    const float VdotH = vr_saturate(-dot3c(s.vi[0], s.vi[1], s.vi[2], Hv[0], Hv[1], Hv[2]) * hs);
+    const float corrAlpha = vr_saturate(s.alpha + 0.5f * tanH);
+    const float dd = (NdotH * NdotH) * (s.a2 - 1.0f) + 1.0f;
+    const float gl = NdotL * (1.0f - s.kk) + s.kk;
+    // D * G * NdotL / 4 * irradiance with D = a2/(pi dd^2) (alpha/corrAlpha)^2, G = 1/(gl gv)
+    const float num = (s.a2 * s.a2) * (NdotL * irr) * (0.25f * VR_INV_PI);
+    const float den = ((corrAlpha * dd) * (corrAlpha * dd)) * (gl * s.gv);
+    const float ks = num * fast_rcp(den);
+    const float om = 1.0f - VdotH;
+    const float om2 = om * om;
+    const float fw = (om2 * om2) * om;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float amb = (a.amb_bot[c] + (a.amb_top[c] - a.amb_bot[c]) * tt) * occlusion;
-        out[c] = (diffuseTerm[c] + amb * albedo[c]) + (specularTerm[c] + amb * F0[c]) + E[c];
+        const float F = s.F0[c] + (1.0f - s.F0[c]) * fw;
+        diffuseTerm[c] += (s.albedo[c] * kd) * color[c];
+        specularTerm[c] += (F * ks) * color[c];
     }
+}
+
+__device__ __forceinline__ void finish_pixel(const DeferredArgs& a, const Surface& s, const float diffuseTerm[3], const float specularTerm[3],
+                                             float out[3])
+{
+#pragma clang fp contract(fast)
+    const float tt = s.N[1] * 0.5f + 0.5f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float amb = (a.amb_bot[c] + (a.amb_top[c] - a.amb_bot[c]) * tt) * s.occlusion;
+        out[c] = (diffuseTerm[c] + amb * s.albedo[c]) + (specularTerm[c] + amb * s.F0[c]) + s.E[c];
+    }
+}
+
+__device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
+                                            uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
+                                            float out[3])
+{
+    const Surface s = decode_surface(a, lut, px, py, depth, diff, spec, n01, n23, e01, e23);
+    float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
+    for (int i = 0; i < a.num_lights; i++) {
+        const DevLight& Lc = a.lights[i];
+        const float* vec = Lc.type == VR_LIGHT_DIRECTIONAL ? Lc.dir : Lc.pos;
+        add_light(s, Lc.type, vec, Lc.inv_range, Lc.color, Lc.intensity, Lc.cosH, Lc.sinH, Lc.tanH, diffuseTerm, specularTerm);
+    }
+    finish_pixel(a, s, diffuseTerm, specularTerm, out);
 }
 
 // PACKED = false: whole frame, row-major output; one lane = 4 consecutive pixels.
@@ -217,6 +247,18 @@ __global__ __launch_bounds__(256) void k_deferred_scalar(DeferredArgs a, const f
     out[p] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
 }
 
+static int fill_light(const vr_light& l, DevLight& d)
+{
+    VR_REQUIRE(l.type == VR_LIGHT_DIRECTIONAL || l.type == VR_LIGHT_POINT, "only directional and point lights are supported");
+    VR_REQUIRE(l.type != VR_LIGHT_POINT || l.radius == 0.0f, "point lights must be punctual (radius 0)");
+    for (int k = 0; k < 3; k++) { d.dir[k] = l.direction[k]; d.pos[k] = l.position[k]; d.color[k] = l.color[k]; }
+    d.type = l.type; d.intensity = l.intensity;
+    d.inv_range = l.type == VR_LIGHT_POINT ? l.angular_size_or_inv_range : 0.0f;
+    const double half = l.type == VR_LIGHT_DIRECTIONAL ? 0.5 * (double)l.angular_size_or_inv_range : 0.0;
+    d.cosH = (float)cos(half); d.sinH = (float)sin(half); d.tanH = (float)tan(half); d.pad = 0.0f;
+    return VR_OK;
+}
+
 extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
                                          int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
                                          vr_image* hdr, const vr_partition* part)
@@ -233,19 +275,9 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
     for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
     a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h;
     a.num_lights = num_lights;
-    for (int i = 0; i < num_lights; i++) {
-        const vr_light& l = lights[i];
-        VR_REQUIRE(l.type == VR_LIGHT_DIRECTIONAL || l.type == VR_LIGHT_POINT, "only directional and point lights are supported");
-        VR_REQUIRE(l.type != VR_LIGHT_POINT || l.radius == 0.0f, "point lights must be punctual (radius 0)");
-        DevLight& d = a.lights[i];
-        for (int k = 0; k < 3; k++) { d.dir[k] = l.direction[k]; d.pos[k] = l.position[k]; d.color[k] = l.color[k]; }
-        d.type = l.type; d.intensity = l.intensity;
-        d.inv_range = l.type == VR_LIGHT_POINT ? l.angular_size_or_inv_range : 0.0f;
-        const double half = l.type == VR_LIGHT_DIRECTIONAL ? 0.5 * (double)l.angular_size_or_inv_range : 0.0;
-        d.cosH = (float)cos(half); d.sinH = (float)sin(half); d.tanH = (float)tan(half); d.pad = 0.0f;
-    }
+    for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], a.lights[i]); if (rc) return rc; }
     const size_t npx = (size_t)gb->w * gb->h;
-    const bool packed = part && part->world_size > 1;
+    const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
     VrKernelScope ks(ctx, VR_K_DEFERRED);
     if (packed) {
         int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
@@ -267,6 +299,185 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
             hipLaunchKernelGGL(k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut);
         }
+    }
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}
+
+// ---- tiled deferred lighting for many point lights (BASELINE config 5) ---------------------------
+// One workgroup = one 16x16 pixel tile, one lane = one pixel.  Phases:
+//   1. decode the surface, reduce the world-space bounding box of the tile's covered pixels
+//      (wave shuffles, then 4 partial boxes through LDS);
+//   2. cull: lane t tests light c*256+t (sphere = position/range vs the tile box; directional lights
+//      always pass); survivors are appended to an LDS list in light order with a wave ballot + popcount
+//      prefix, and their constants are staged in LDS (48 B each);
+//   3. shade: every lane walks the tile's list (LDS broadcast reads) with the same BRDF as k_deferred.
+// A light culled here has zero attenuation for every pixel of the tile, so the sum equals the
+// all-lights loop of the oracle.
+constexpr int kLightTile = 16;
+constexpr int kTileLightCap = 1024;
+struct TiledLight { float vec[3]; float inv_range; float color[3]; float intensity; float cosH, sinH, tanH; int type; };
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
+                                                         const float* __restrict__ g_depth, const uint32_t* __restrict__ g_diff,
+                                                         const uint32_t* __restrict__ g_spec, const uint2* __restrict__ g_nrm,
+                                                         const uint2* __restrict__ g_emi, uint2* __restrict__ out,
+                                                         const float* __restrict__ lut_g, const int32_t* __restrict__ owned_tiles,
+                                                         uint32_t* __restrict__ overflow_flag)
+{
+    __shared__ float lut[256];
+    __shared__ TiledLight s_light[kTileLightCap];
+    __shared__ float s_box[4][6];
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint32_t s_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lut[tid] = lut_g[tid];
+    if (tid == 0) s_count = 0u;
+
+    int px, py; size_t out_index;
+    const int lx = tid & 15, ly = tid >> 4;
+    if (PACKED) {
+        const int sub = VR_OWNER_TILE / kLightTile;                  // 8 light tiles per owner-tile side
+        const int lt = blockIdx.x / (sub * sub), st = blockIdx.x - lt * (sub * sub);
+        const int tile = owned_tiles[lt];
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int ox = (st % sub) * kLightTile + lx, oy = (st / sub) * kLightTile + ly;
+        px = tx * VR_OWNER_TILE + ox; py = ty * VR_OWNER_TILE + oy;
+        out_index = ((size_t)lt * VR_OWNER_TILE + oy) * VR_OWNER_TILE + ox;
+    } else {
+        const int tiles_x = (a.w + kLightTile - 1) / kLightTile;
+        const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+        px = tx * kLightTile + lx; py = ty * kLightTile + ly;
+        out_index = (size_t)py * a.w + px;
+    }
+    const bool inside = px < a.w && py < a.h;
+    __syncthreads();
+
+    Surface s;
+    bool covered = false;
+    if (inside) {
+        const size_t p = (size_t)py * a.w + px;
+        const float depth = g_depth[p];
+        const uint2 n = g_nrm[p], e = g_emi[p];
+        s = decode_surface(a, lut, px, py, depth, g_diff[p], g_spec[p], n.x, n.y, e.x, e.y);
+        covered = depth < 1.0f;                                      // background pixels receive no light (albedo = F0 = N = 0)
+    }
+    // ---- 1. tile bounding box in world space
+    const float big = 3.0e38f;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { lo[c] = covered ? s.wp[c] : big; hi[c] = covered ? s.wp[c] : -big; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], __shfl_xor(lo[c], off)); hi[c] = vr_max(hi[c], __shfl_xor(hi[c], off)); }
+    }
+    if (lane == 0) { for (int c = 0; c < 3; c++) { s_box[wave][c] = lo[c]; s_box[wave][3 + c] = hi[c]; } }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        lo[c] = vr_min(vr_min(s_box[0][c], s_box[1][c]), vr_min(s_box[2][c], s_box[3][c]));
+        hi[c] = vr_max(vr_max(s_box[0][3 + c], s_box[1][3 + c]), vr_max(s_box[2][3 + c], s_box[3][3 + c]));
+    }
+    const bool any_covered = lo[0] <= hi[0];
+
+    // ---- 2. cull, 256 lights per round, list kept in light order
+    for (int base = 0; base < num_lights && any_covered; base += 256) {
+        const int li = base + tid;
+        bool keep = false;
+        DevLight L;
+        if (li < num_lights) {
+            L = lights[li];
+            if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) keep = true;
+            else {
+                float d2 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const float d = vr_max(vr_max(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
+                const float r = 1.0f / L.inv_range;
+                keep = d2 <= (r * r) * 1.0001f;                      // attenuation is exactly 0 from the range outwards
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = s_count;
+        for (int w = 0; w < wave; w++) before += s_wave_count[w];
+        const uint32_t total = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+        if (keep) {
+            const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < (uint32_t)kTileLightCap) {
+                TiledLight t;
+                const float* v = L.type == VR_LIGHT_DIRECTIONAL ? L.dir : L.pos;
+                t.vec[0] = v[0]; t.vec[1] = v[1]; t.vec[2] = v[2]; t.inv_range = L.inv_range;
+                t.color[0] = L.color[0]; t.color[1] = L.color[1]; t.color[2] = L.color[2]; t.intensity = L.intensity;
+                t.cosH = L.cosH; t.sinH = L.sinH; t.tanH = L.tanH; t.type = L.type;
+                s_light[slot] = t;
+            } else atomicOr(overflow_flag, 1u);
+        }
+        __syncthreads();
+        if (tid == 0) s_count = min(s_count + total, (uint32_t)kTileLightCap);
+        __syncthreads();
+    }
+
+    // ---- 3. shade
+    if (!inside) return;
+    float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
+    if (covered) {
+        const uint32_t n = s_count;
+        for (uint32_t i = 0; i < n; i++) {
+            const TiledLight& t = s_light[i];
+            add_light(s, t.type, t.vec, t.inv_range, t.color, t.intensity, t.cosH, t.sinH, t.tanH, diffuseTerm, specularTerm);
+        }
+    }
+    float rgb[3];
+    finish_pixel(a, s, diffuseTerm, specularTerm, rgb);
+    out[out_index] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
+}
+
+extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
+                                               int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
+                                               vr_image* hdr, const vr_partition* part)
+{
+    VR_REQUIRE(ctx && view && gb && hdr && amb_top && amb_bottom, "NULL argument");
+    VR_REQUIRE(num_lights >= 0 && num_lights <= 65536 && (num_lights == 0 || lights), "bad light list");
+    VR_REQUIRE(view->viewport_w == gb->w && view->viewport_h == gb->h && view->viewport_x == 0 && view->viewport_y == 0,
+               "view viewport must cover the G-buffer");
+    VR_HIP(hipSetDevice(ctx->device));
+    if ((size_t)num_lights > ctx->light_capacity) {
+        VR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_lights); ctx->d_lights = nullptr; ctx->light_capacity = 0;
+        const size_t cap = (size_t)num_lights < 1024 ? 1024 : (size_t)num_lights;
+        VR_HIP(hipMalloc(&ctx->d_lights, cap * sizeof(DevLight)));
+        ctx->light_capacity = cap;
+    }
+    if (!ctx->d_flags) { VR_HIP(hipMalloc(&ctx->d_flags, 64)); VR_HIP(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream)); }
+    ctx->h_lights.resize((size_t)num_lights);
+    for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i]); if (rc) return rc; }
+    if (num_lights) VR_HIP(hipMemcpyAsync(ctx->d_lights, ctx->h_lights.data(), (size_t)num_lights * sizeof(DevLight), hipMemcpyHostToDevice, ctx->stream));
+    DeferredArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 16; i++) a.c2w[i] = view->clip_to_world[i];
+    for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
+    a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h; a.num_lights = 0;
+    const bool packed = part != nullptr;
+    VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
+    if (packed) {
+        int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
+        if (rc) return rc;
+        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 8 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
+        a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+        const int sub = VR_OWNER_TILE / kLightTile;
+        if (ctx->num_owned > 0)
+            hipLaunchKernelGGL(k_deferred_tiled<true>, dim3((unsigned)ctx->num_owned * sub * sub), dim3(256), 0, ctx->stream, a, ctx->d_lights,
+                               num_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
+                               ctx->d_srgb_lut, ctx->d_owned_tiles, ctx->d_flags);
+    } else {
+        VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
+        const int tx = (gb->w + kLightTile - 1) / kLightTile, ty = (gb->h + kLightTile - 1) / kLightTile;
+        hipLaunchKernelGGL(k_deferred_tiled<false>, dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
+                           (const int32_t*)nullptr, ctx->d_flags);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;

@@ -62,6 +62,7 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); (void)hipFree(c->d_enc_tab);
+    (void)hipFree(c->d_lights); (void)hipFree(c->d_flags);
     (void)hipFree(c->d_owned_tiles); (void)hipFree(c->d_tile_slot); (void)hipFree(c->d_raster_tiles);
     timing_reset(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -132,7 +133,7 @@ extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT],
 extern "C" VR_API const char* vr_kernel_name(int id)
 {
     static const char* names[VR_K_COUNT] = { "k_select", "k_vertex", "k_setup", "k_clip", "k_scan", "k_fill", "k_raster",
-                                              "k_deferred", "k_detile", "k_fill_u32 (clear)" };
+                                              "k_deferred", "k_detile", "k_fill_u32 (clear)", "k_deferred_tiled" };
     return (id >= 0 && id < VR_K_COUNT) ? names[id] : "?";
 }
 

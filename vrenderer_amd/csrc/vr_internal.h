@@ -87,6 +87,9 @@ struct vr_context {
     int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
     int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64) inside owned owner tiles
     int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+    // light list of vr_deferred_light_tiled
+    DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights;
+    uint32_t* d_flags = nullptr;
     // per-kernel timing (vr_timing_*): event pairs recorded on `stream`
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;     // reusable events

@@ -272,6 +272,32 @@ class DeferredLightingPass:
                                              C.byref(partition) if partition is not None else None), "vr_deferred_light")
 
 
+class TiledDeferredLightingPass(DeferredLightingPass):
+    """DeferredLightingPass for many lights (BASELINE config 5): per-tile LDS light culling."""
+
+    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None):
+        n = len(lights)
+        arr = (Light * max(n, 1))(*lights)
+        check(self.ctx.lib.vr_deferred_light_tiled(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
+                                                   _f3(ambient_top), _f3(ambient_bottom), output.handle,
+                                                   C.byref(partition) if partition is not None else None),
+              "vr_deferred_light_tiled")
+
+
+def synthetic_point_lights(n, world_size, heightmap, max_height=400.0, seed=9001):
+    """positions uniform in the world xz-square at terrain height + U(2,30), range U(20,80),
+    colour uniform; numpy PCG64 with a fixed seed."""
+    rng = np.random.default_rng(seed)
+    size = heightmap.shape[0]
+    xz = rng.uniform(-0.5 * world_size, 0.5 * world_size, (n, 2))
+    tx = np.clip(((xz[:, 0] / world_size + 0.5) * size).astype(int), 0, size - 1)
+    tz = np.clip(((xz[:, 1] / world_size + 0.5) * size).astype(int), 0, size - 1)
+    y = heightmap[tz, tx].astype(np.float64) / 255.0 * max_height + rng.uniform(2.0, 30.0, n)
+    rad = rng.uniform(20.0, 80.0, n)
+    col = rng.uniform(0.0, 1.0, (n, 3))
+    return [point_light((xz[i, 0], y[i], xz[i, 1]), 400.0, rad[i], col[i]) for i in range(n)]
+
+
 def synth_heightmap(ctx, size, seed=1337):
     out = np.empty((size, size), np.uint8)
     check(ctx.lib.vr_synth_heightmap(ctx.handle, size, seed, _vp(out)), "vr_synth_heightmap")
