@@ -252,6 +252,10 @@ VR_API int vr_synth_heightmap(vr_context* ctx, int32_t size, uint32_t seed, uint
 VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
                            const uint8_t* height_r8, uint8_t* out_srgba8);
 
+/* diagnostics of the last vr_terrain_render (synchronises): out[0] selected nodes, [1] status flags,
+ * [2] clipper sub-triangles, [3] clipper vertices, [4] triangles sent to the clipper, [5] bin entries,
+ * [6] largest bin, [7] non-empty bins */
+VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8]);
 /* test helper: the device's linear -> sRGB8 render-target conversion applied to n host floats */
 VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, size_t n, uint8_t* out);
 

@@ -22,7 +22,7 @@ def run(name, rp, frames, deferred=True, clear=False):
             if deferred: dl.Render(views[i], rt, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
         ctx.synchronize()
     t = ctx.timing_collect(); ctx.timing_enable(False)
-    print(name, {k: round(ms / n * 1e3, 1) for k, (ms, n) in t.items()}, 'nodes', tp.num_chunks(), flush=True)
+    print(name, {k: round(ms / n * 1e3, 1) for k, (ms, n) in t.items()}, tp.render_stats(), flush=True)
 fr = list(range(0, 120, 12))
 run("fused-clear      ", vr.default_render_params(400.0, assume_cleared=1), fr)
 run("clear+render     ", vr.default_render_params(400.0), fr, clear=True)

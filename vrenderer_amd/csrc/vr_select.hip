@@ -293,3 +293,18 @@ extern "C" VR_API int vr_terrain_num_chunks(vr_terrain* t, uint32_t* count)
     if (!t->have_selection) { *count = 0; return VR_OK; }
     return read_counters(t, count);
 }
+
+extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
+{
+    VR_REQUIRE(t && out, "NULL argument");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    VR_HIP(hipStreamSynchronize(t->ctx->stream));
+    VR_HIP(hipMemcpy(out, t->d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out[6] = 0; out[7] = 0;
+    if (t->scratch_tiles > 0 && t->d_tile_count) {
+        std::vector<uint32_t> c((size_t)t->scratch_tiles);
+        VR_HIP(hipMemcpy(c.data(), t->d_tile_count, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t v : c) { if (v > out[6]) out[6] = v; if (v) out[7]++; }
+    }
+    return VR_OK;
+}

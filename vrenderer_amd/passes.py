@@ -246,6 +246,12 @@ class TerrainPass:
                                              render_targets.handle, C.byref(render_params),
                                              C.byref(partition) if partition is not None else None), "vr_terrain_render")
 
+    def render_stats(self):
+        out = (C.c_uint32 * 8)()
+        check(self.ctx.lib.vr_debug_render_stats(self.handle, out), "vr_debug_render_stats")
+        keys = ("nodes", "flags", "clip_subtris", "clip_verts", "clipped_tris", "bin_entries", "max_bin", "nonempty_bins")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def num_chunks(self):
         """EditorParams::m_NumChunks (TerrainPass.cpp:198); synchronises."""
         n = C.c_uint32()
