@@ -140,7 +140,9 @@ def main():
         # packed tile-major buffer: max_owned tiles of 128x128 RGBA16F, equal on every rank
         hdr = vr.HdrImage(ctx, vr.VR_OWNER_TILE, info["max_owned"] * vr.VR_OWNER_TILE, external_ptr=packed.data_ptr())
         frame = vr.HdrImage(ctx, W, H)
-        owned_px = info["owned"] * vr.VR_OWNER_TILE * vr.VR_OWNER_TILE
+        from vrenderer_amd import partition as pt
+        tx_ = pt.owner_grid(W, H)[0]
+        owned_px = sum(min(128, W - (t % tx_) * 128) * min(128, H - (t // tx_) * 128) for t in pt.owned_tiles(W, H, rank, world))
     else:
         hdr = vr.HdrImage(ctx, W, H)
         frame = hdr
@@ -204,6 +206,15 @@ def main():
         total_kernel_ms = sum(ms for ms, _ in timings.values())
         dominant = max(timings.items(), key=lambda kv: kv[1][0])[0] if timings else None
 
+        # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for wide
+        # reads, + WRITE_SIZE; see tools/summarize_pmc.py).  They were taken on the N=1 8K workload.
+        pmc = {}
+        try:
+            if world == 1 and (W, H) == (7680, 4320):
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pmc = {}
+
         def roof(name, bytes_per_px, px):
             if name not in timings:
                 return None
@@ -211,7 +222,8 @@ def main():
             avg_s = ms / n * 1e-3
             ach = bytes_per_px * px / avg_s / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_s * 1e6, 2),
+                    "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"), "avg_us": round(avg_s * 1e6, 2),
                     "bytes_per_launch": bytes_per_px * px,
                     "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"}
 

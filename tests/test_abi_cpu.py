@@ -117,3 +117,34 @@ def test_pack_detile_roundtrip_numpy():
         frame = rng.integers(0, 65535, (h, w, 4), dtype=np.uint16)
         gathered = np.concatenate([pt.pack(frame, r, world) for r in range(world)], 0)
         assert np.array_equal(pt.detile(gathered, w, h, world), frame)
+
+
+def _build_host_example(tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "frame_example")
+    lib_dir = os.path.join(ROOT, "vrenderer_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "host", "frame_example.cpp"), "-o", exe,
+           "-L", lib_dir, "-lvrterrain", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_cpp_host_example_compiles_links_and_fails_soft_without_gpu(product_lib, tmp_path):
+    """The header is usable from C++ and the library links; without a device the example reports it."""
+    import subprocess
+    exe = _build_host_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if _has_gpu(product_lib):
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 0 and "no device" in r.stdout, r.stdout + r.stderr
+
+
+def test_header_is_valid_c(tmp_path):
+    import subprocess
+    src = tmp_path / "c_check.c"
+    src.write_text('#include <vrterrain.h>\nint main(void) { vr_view v; vr_light l; (void)v; (void)l; return sizeof(vr_instance) == 112 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                    str(tmp_path / "c_check")], check=True, capture_output=True, text=True)
+    assert subprocess.run([str(tmp_path / "c_check")]).returncode == 0

@@ -356,3 +356,13 @@ def test_tiled_deferred_1024_lights_matches_oracle(scene256, oracle, gpu_ctx):
     assert np.array_equal(hdr2.download(), full)
     for o in (big, hdr, hdr2, rt):
         o.close()
+
+
+def test_cpp_host_example(product_lib, tmp_path):
+    """The C++ caller of tests/host/frame_example.cpp renders and lights a frame through the C ABI."""
+    import subprocess
+    from tests.test_abi_cpu import _build_host_example
+    exe = _build_host_example(tmp_path)
+    r = subprocess.run([exe, "--require-gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "chunks=" in r.stdout
