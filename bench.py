@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--size", type=int, default=2048, help="heightmap / world size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: run the all-gather + de-tile of frame i on the render stream instead of overlapping it with frame i+1")
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, packed tiles, all-gather, de-tile) even with one rank")
@@ -115,7 +117,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import vrenderer_amd as vr
-    from vrenderer_amd.passes import frame_detile, partition_info
+    from vrenderer_amd.passes import frame_detile, partition_info, partition_prepare
     from tests.common import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
 
     W, H, size = args.width, args.height, args.size
@@ -132,14 +134,29 @@ def main():
     rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
 
     part = None
+    ctx_comm = ctx
     if use_dist:
         part = vr.Partition(rank, world)
         info = partition_info(W, H, rank, world)
-        packed = torch.empty(info["packed_bytes"] // 2, dtype=torch.float16, device="cuda")
-        gathered = torch.empty(world * info["packed_bytes"] // 2, dtype=torch.float16, device="cuda")
+        # Double-buffered exchange: frame i's all-gather + de-tile run on a side stream while frame
+        # i+1 is rendered (the collective reads packed[b] / writes gathered[b], the renderer does not).
+        nbuf = 1 if args.no_overlap else 2
+        half_elems = info["packed_bytes"] // 2
+        packed = [torch.empty(half_elems, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
+        gathered = [torch.empty(world * half_elems, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
         # packed tile-major buffer: max_owned tiles of 128x128 RGBA16F, equal on every rank
-        hdr = vr.HdrImage(ctx, vr.VR_OWNER_TILE, info["max_owned"] * vr.VR_OWNER_TILE, external_ptr=packed.data_ptr())
-        frame = vr.HdrImage(ctx, W, H)
+        hdr_bufs = [vr.HdrImage(ctx, vr.VR_OWNER_TILE, info["max_owned"] * vr.VR_OWNER_TILE, external_ptr=t.data_ptr()) for t in packed]
+        main_stream = torch.cuda.current_stream()
+        if nbuf > 1:
+            comm_stream = torch.cuda.Stream()
+            ctx_comm = vr.Context(local_rank)
+            ctx_comm.set_stream(comm_stream.cuda_stream)
+        else:
+            comm_stream = main_stream
+        partition_prepare(ctx_comm, W, H, part)
+        frame = vr.HdrImage(ctx_comm, W, H)
+        render_done = [torch.cuda.Event() for _ in range(nbuf)]
+        comm_done = [torch.cuda.Event() for _ in range(nbuf)]
         from vrenderer_amd import partition as pt
         tx_ = pt.owner_grid(W, H)[0]
         owned_px = sum(min(128, W - (t % tx_) * 128) * min(128, H - (t // tx_) * 128) for t in pt.owned_tiles(W, H, rank, world))
@@ -155,11 +172,20 @@ def main():
 
     def step(i):
         v = views[i % 120]
+        if not use_dist:
+            tp.Render(v, v, rt, rp, None)
+            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, None)
+            return
+        b = i % nbuf
+        main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
         tp.Render(v, v, rt, rp, part)
-        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, part)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, packed)
-            frame_detile(ctx, gathered.data_ptr(), world, frame)
+        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_bufs[b], part)
+        render_done[b].record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(render_done[b])
+            dist.all_gather_into_tensor(gathered[b], packed[b])      # RCCL over xGMI, equal send counts
+            frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
+            comm_done[b].record(comm_stream)
 
     def sync():
         if use_dist:
@@ -173,6 +199,8 @@ def main():
         step(i)
     sync()
     ctx.timing_enable(True)          # HIP events around every kernel, on the stream they are launched on
+    if ctx_comm is not ctx:
+        ctx_comm.timing_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -180,6 +208,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timings = ctx.timing_collect()
     ctx.timing_enable(False)
+    if ctx_comm is not ctx:
+        timings.update(ctx_comm.timing_collect())
+        ctx_comm.timing_enable(False)
     n_nodes = tp.num_chunks()
 
     verified = None
@@ -237,7 +268,8 @@ def main():
                                    f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
                                    + ("+all-gather+detile" if use_dist else ""),
                        "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,
-                       "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"},
+                       "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"
+                                      + (", all-gather of frame i overlapped with rendering of frame i+1" if use_dist and not args.no_overlap else "")},
             # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
             "roofline": roof_deferred,
             "roofline_gbuffer_fill": roof_raster,

@@ -240,6 +240,9 @@ VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_par
                                      int32_t* tiles_x, int32_t* tiles_y, int32_t* owned,
                                      int32_t* max_owned);
 VR_API size_t vr_partition_packed_bytes(int32_t width, int32_t height, int32_t world_size);
+/* Builds the partition tables of a context up front (they are otherwise built on first use by
+ * vr_terrain_render / vr_deferred_light); needed when vr_frame_detile runs on its own context/stream. */
+VR_API int    vr_partition_prepare(vr_context* ctx, int32_t width, int32_t height, const vr_partition* part);
 /* After the all-gather: gathered = world_size consecutive packed buffers (device
  * pointer); rebuilds the row-major RGBA16F frame. */
 VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int32_t world_size,

@@ -114,7 +114,7 @@ EXPORTS = [
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_partition_num_tiles",
-    "vr_partition_packed_bytes", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_render_stats",
+    "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_render_stats",
 ]
 
 _lib = None
@@ -182,6 +182,7 @@ def load_library():
         "vr_partition_num_tiles": (C.c_int, [C.c_int32, C.c_int32, P(Partition), P(C.c_int32), P(C.c_int32),
                                              P(C.c_int32), P(C.c_int32)]),
         "vr_partition_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+        "vr_partition_prepare": (C.c_int, [vp, C.c_int32, C.c_int32, P(Partition)]),
         "vr_frame_detile": (C.c_int, [vp, vp, C.c_int32, vp]),
         "vr_synth_heightmap": (C.c_int, [vp, C.c_int32, C.c_uint32, vp]),
         "vr_synth_albedo": (C.c_int, [vp, C.c_int32, C.c_uint32, vp, vp]),

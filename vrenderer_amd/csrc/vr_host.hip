@@ -415,6 +415,12 @@ extern "C" VR_API size_t vr_partition_packed_bytes(int32_t w, int32_t h, int32_t
     return (size_t)mo * VR_OWNER_TILE * VR_OWNER_TILE * 8;
 }
 
+extern "C" VR_API int vr_partition_prepare(vr_context* ctx, int32_t w, int32_t h, const vr_partition* part)
+{
+    VR_REQUIRE(ctx && w > 0 && h > 0, "bad arguments");
+    return vr_ensure_partition(ctx, w, h, part);
+}
+
 int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part)
 {
     int world = part ? part->world_size : 1, rank = part ? part->rank : 0;

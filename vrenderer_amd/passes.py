@@ -327,5 +327,9 @@ def partition_info(width, height, rank, world):
                 packed_bytes=lib.vr_partition_packed_bytes(width, height, world))
 
 
+def partition_prepare(ctx, width, height, partition):
+    check(ctx.lib.vr_partition_prepare(ctx.handle, width, height, C.byref(partition)), "vr_partition_prepare")
+
+
 def frame_detile(ctx, gathered_ptr, world, frame):
     check(ctx.lib.vr_frame_detile(ctx.handle, C.c_void_p(gathered_ptr), world, frame.handle), "vr_frame_detile")
