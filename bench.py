@@ -282,6 +282,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)
+                # the device counterpart of the reference's (disabled) heightmap update, for the same heightmap
+                ctx.timing_enable(True)
+                tp.SetHeight(True)
+                th = ctx.timing_collect()
+                tp.SetHeight(False)
+                ctx.timing_enable(False)
+                out["cpu_baseline"]["reference_cpu_side"]["device_set_height_minmax_us"] = round(
+                    sum(ms for ms, _ in th.values()) * 1e3, 1)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -149,7 +149,7 @@ VR_API const char* vr_version(void);
  * the reference's PROFILE_GPU_SCOPE timestamp queries (Profiler.h:55-125,
  * Renderer.cpp:326-437).  Kernel ids: */
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
-       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_COUNT };
+       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS, VR_K_COUNT };
 VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
 /* Synchronises the stream; per kernel id: summed milliseconds and launch count since
  * the last enable/collect; resets the samples. */
@@ -180,6 +180,15 @@ VR_API int  vr_terrain_lod_ranges(const vr_terrain* t, float out[VR_MAX_LODS]); 
  * 1 albedo SRGBA8); *w,*h receive the level size; host may be NULL to query sizes. */
 VR_API int  vr_terrain_download_mip(vr_terrain* t, int which, int level, void* host, size_t bytes,
                                     int32_t* w, int32_t* h, int32_t* levels);
+
+/* QuadTree::SetHeight for every node (QuadTree.cpp:164-208) as a device reduction over the heightmap,
+ * and m_HeightLoaded (QuadTree.h:70).  The reference wrote this and left its launch commented out
+ * (QuadTree.cpp:46-51), so the default is "not loaded": cull boxes span y in [0, camera.y].  With
+ * enable != 0 the per-node (position.y, extents.y) are computed and NodeSelect culls with
+ * [min.y, max.y] * max_height (QuadTree.cpp:87-91); UpdateTransforms then carries them too. */
+VR_API int  vr_terrain_update_heights(vr_terrain* t, int enable);
+/* test helper: (position.y, extents.y) of node ids [first, first+count) */
+VR_API int  vr_terrain_download_node_heights(vr_terrain* t, uint32_t first, uint32_t count, float* out);
 
 /* QuadTree::ClearSelectedNodes + NodeSelect + TerrainPass::UpdateTransforms +
  * EditorParams::m_NumChunks (TerrainPass.cpp:173-198, QuadTree.cpp:80-131).

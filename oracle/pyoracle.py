@@ -50,6 +50,8 @@ def lib():
     L.orc_select.argtypes = [vp, P(View), C.c_float, C.c_int, vp, vp, C.c_int]
     L.orc_set_height.argtypes = [vp]
     L.orc_node_height.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float)]
+    L.orc_set_height_loaded.argtypes = [vp, C.c_int]
+    L.orc_node_heights.argtypes = [vp, vp, C.c_long]
     L.orc_view_from_camera.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float, C.c_float, C.c_float,
                                        C.c_int, C.c_int, P(View)]
     L.orc_vertex.argtypes = [vp, P(View), C.c_float, P(Instance), C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
@@ -165,6 +167,16 @@ class OracleTerrain:
         w, h = C.c_int(), C.c_int()
         p = lib().orc_terrain_albedo_mip(self.handle, level, C.byref(w), C.byref(h))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+
+    def set_height(self, loaded=True):
+        """QuadTree::SetHeight over the whole tree + m_HeightLoaded (QuadTree.cpp:46-51,191-208)."""
+        lib().orc_set_height(self.handle)
+        lib().orc_set_height_loaded(self.handle, int(loaded))
+
+    def node_heights(self):
+        out = np.zeros((self.num_nodes, 2), np.float32)
+        lib().orc_node_heights(self.handle, _ptr(out), self.num_nodes)
+        return out
 
     def height_levels(self):
         return lib().orc_terrain_height_levels(self.handle)

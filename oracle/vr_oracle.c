@@ -453,6 +453,16 @@ int orc_select(orc_terrain* t, const vr_view* v, float max_height, int stub_frus
 }
 
 void orc_set_height(orc_terrain* t) { set_height(t, t->root, 0); }
+/* m_HeightLoaded = true is what the reference's (commented-out) async task sets after SetHeight
+ * (QuadTree.cpp:46-51); NodeSelect then culls with the node's real y-bounds (:87-91). */
+void orc_set_height_loaded(orc_terrain* t, int loaded) { t->height_loaded = loaded; }
+static void dump_heights(const orc_node* n, float* out, long max_ids)
+{
+    if (!n) return;
+    if ((long)n->id < max_ids) { out[2 * n->id] = n->pos[1]; out[2 * n->id + 1] = n->ext[1]; }
+    for (int i = 0; i < 4; i++) dump_heights(n->child[i], out, max_ids);
+}
+void orc_node_heights(const orc_terrain* t, float* out, long max_ids) { dump_heights(t->root, out, max_ids); }
 int orc_node_height(const orc_terrain* t, uint32_t id, float* py, float* ey)
 {
     /* walk down from the root following the id's (depth, ix, iz) */

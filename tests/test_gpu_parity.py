@@ -366,3 +366,38 @@ def test_cpp_host_example(product_lib, tmp_path):
     r = subprocess.run([exe, "--require-gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "chunks=" in r.stdout
+
+
+@pytest.mark.parametrize("scene_name", ["scene256", "scene2048"])
+def test_node_heights_and_height_aware_select(scene_name, request, oracle, gpu_ctx):
+    """Row f2: QuadTree::SetHeight as a device reduction (bit-exact per node) and NodeSelect with
+    m_HeightLoaded = true (tight y-bounds), plus the instance transforms that then carry y."""
+    sc = request.getfixturevalue(scene_name)
+    ot, tp, size = sc["ot"], sc["tp"], sc["size"]
+    try:
+        ot.set_height(True)
+        tp.SetHeight(True)
+        want = ot.node_heights()
+        got = tp.node_heights(0, ot.num_nodes)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert want[0, 1] > 0, "root extents.y must be non-zero on a non-flat heightmap"
+        fewer = 0
+        for cam in CAMERAS:
+            eye, tgt = scaled_camera(cam, size)
+            v = vr.make_view(eye, tgt, 1920, 1080)
+            n_o, ids_o, inst_o = ot.select(v, 400.0)
+            n_g, ids_g, inst_g = tp.NodeSelect(v, 400.0)
+            assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), cam
+            ot.set_height(False)
+            n_loose, _, _ = ot.select(v, 400.0)
+            ot.set_height(True)
+            fewer += n_loose != n_o
+        assert fewer > 0, "tight bounds should change the selection for at least one camera"
+        if size == 256:
+            eye, tgt = scaled_camera(CAMERAS[5], size)
+            v, gb_o, planes, n_o, n_g = _render_both(sc, oracle, gpu_ctx, eye, tgt, 480, 270)
+            assert n_o == n_g
+            _assert_gbuffer_equal(gb_o, planes, "height-aware frame")
+    finally:
+        ot.set_height(False)
+        tp.SetHeight(False)

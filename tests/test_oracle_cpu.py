@@ -289,3 +289,27 @@ def test_partitioned_render_equals_unsplit(oracle, t256):
         assert np.array_equal(gb.depth[own], full.depth[own]) and np.array_equal(gb.diffuse[own], full.diffuse[own])
         assert (gb.depth[~own] == 1.0).all() and not gb.diffuse[~own].any(), "a rank touched pixels it does not own"
     assert (seen == 1).all()
+
+
+def test_set_height_known_answers(oracle, t256):
+    """QuadTree::SetHeight (QuadTree.cpp:164-208): the root spans the whole heightmap, a leaf one texel."""
+    h = oracle.synth_heightmap(256)
+    try:
+        t256.set_height(True)
+        nh = t256.node_heights()
+        mn, mx = np.float32(h.min()) / np.float32(255), np.float32(h.max()) / np.float32(255)
+        ext = (mx - mn) / np.float32(2)
+        assert nh[0, 1] == ext and nh[0, 0] == mn + ext
+        L = t256.num_lods
+        base = (4 ** L - 1) // 3
+        for (ix, iz) in ((0, 0), (17, 200), (255, 255)):
+            py, ey = nh[base + iz * 256 + ix]
+            assert ey == 0.0 and py == 0.0          # single texel: max - min == 0 -> min forced to 0 (QuadTree.cpp:186)
+        d = L - 1                                    # 2x2 texel nodes
+        b1 = (4 ** d - 1) // 3
+        blk = h[0:2, 0:2].astype(np.float32) / np.float32(255)
+        e1 = (blk.max() - blk.min()) / np.float32(2)
+        exp_pos = (np.float32(0) if blk.max() == blk.min() else blk.min()) + e1
+        assert nh[b1, 1] == e1 and nh[b1, 0] == exp_pos
+    finally:
+        t256.set_height(False)

@@ -143,6 +143,10 @@ struct vr_terrain {
     size_t bin_capacity = 0;
     int scratch_tiles = 0;
     bool have_selection = false;
+    // QuadTree::SetHeight results: (position.y, extents.y) per node id; m_HeightLoaded
+    float2* d_node_heights = nullptr;
+    bool height_loaded = false;
+    float texel_size[2] = { 0.0f, 0.0f };   // m_TexelSize (QuadTree.cpp:29)
 };
 
 // ---- cross-TU entry points ----------------------------------------------------------

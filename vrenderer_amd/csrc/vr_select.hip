@@ -28,7 +28,7 @@ struct SelectArgs {
     float half_w, half_h;        // root extents (m_Width/2, m_Height/2)
     int num_lods;
     int max_instances;
-    int height_loaded;           // m_HeightLoaded (always 0 until row f2)
+    int height_loaded;           // m_HeightLoaded
     float max_height;
 };
 
@@ -73,8 +73,14 @@ __device__ __forceinline__ bool box_in_frustum(const SelectArgs& a, float mnx, f
     return true;
 }
 
+__device__ __forceinline__ uint32_t node_id_of(const NodeGeom& g, int depth)
+{
+    return (uint32_t)((((uint64_t)1 << (2 * depth)) - 1) / 3) + g.iz * (1u << depth) + g.ix;
+}
+
 __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* __restrict__ node_ids,
-                                                        vr_instance* __restrict__ inst, uint32_t* __restrict__ counters)
+                                                        vr_instance* __restrict__ inst, uint32_t* __restrict__ counters,
+                                                        const float2* __restrict__ heights)
 {
     __shared__ uint32_t frontier[2][kFrontierCap];
     __shared__ uint32_t selected[kSelectedCap];
@@ -98,6 +104,10 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
                 select_self = depth > 0;
             } else {
                 float mny = 0.0f, mxy = a.cam[1];                 // m_HeightLoaded == false (QuadTree.cpp:92-96)
+                if (a.height_loaded) {                            // QuadTree.cpp:87-91
+                    const float2 hy = heights[node_id_of(g, depth)];
+                    mny = (hy.x - hy.y) * a.max_height; mxy = (hy.x + hy.y) * a.max_height;
+                }
                 if (box_in_frustum(a, g.px - g.ex, mny, g.pz - g.ez, g.px + g.ex, mxy, g.pz + g.ez)) {
                     if (lod == 0) select_self = true;                                   // :106-111
                     else if (!node_in_range(g, a.cam, a.range2[lod - 1])) select_self = true;   // :114-118
@@ -136,15 +146,17 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         int depth = (int)(key & 15u);
         uint32_t path = (key >> 4) >> (2 * (L - depth));
         NodeGeom g = node_from_path(a, path, depth);
-        uint32_t base = (uint32_t)((((uint64_t)1 << (2 * depth)) - 1) / 3);
-        node_ids[rank] = base + g.iz * (1u << depth) + g.ix;
+        const uint32_t id = node_id_of(g, depth);
+        node_ids[rank] = id;
+        float py = a.loc[1], ey = 0.0f;
+        if (a.height_loaded) { const float2 hy = heights[id]; py = hy.x; ey = hy.y; }
         // scaling(extents) * translation(position) -> float3x4 rows (TerrainPass.cpp:245-253)
         vr_instance o;
         o.padding = 0u; o.first_geometry_instance_index = 0u; o.first_geometry_index = 0u; o.num_geometries = 1u;
 #pragma unroll
         for (int k = 0; k < 12; k++) { o.transform[k] = 0.0f; o.prev_transform[k] = 0.0f; }
         o.transform[0] = g.ex; o.transform[3] = g.px;
-        o.transform[5] = 0.0f; o.transform[7] = a.loc[1];
+        o.transform[5] = ey; o.transform[7] = py;
         o.transform[10] = g.ez; o.transform[11] = g.pz;
         inst[rank] = o;
     }
@@ -164,11 +176,135 @@ int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
     for (int i = 0; i < 6; i++) for (int j = 0; j < 4; j++) a.planes[i][j] = view->planes[i][j];
     for (int i = 0; i < VR_MAX_LODS; i++) a.range2[i] = t->lod_ranges[i] * t->lod_ranges[i];
     a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f;
-    a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.height_loaded = 0; a.max_height = max_height;
+    a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.max_height = max_height;
+    a.height_loaded = (t->height_loaded && t->d_node_heights) ? 1 : 0;
     VrKernelScope ks(t->ctx, VR_K_SELECT);
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters,
+                       (const float2*)t->d_node_heights);
     VR_HIP(hipGetLastError());
     t->have_selection = true;
+    return VR_OK;
+}
+
+// ---- QuadTree::SetHeight on the device (QuadTree.cpp:164-208) ----------------------------------
+struct HeightArgs {
+    float loc[3]; float half_w, half_h; float world_size; float texel_x, texel_y;
+    int tex_w, tex_h; int depth;
+};
+
+// texel rectangle of a node, exactly as GetMinMaxHeightValue computes it
+__device__ __forceinline__ void node_texel_rect(const HeightArgs& a, const NodeGeom& g, int& x0, int& x1, int& y0, int& y1)
+{
+    const float width = g.ex * 2.0f, height = g.ez * 2.0f;
+    float minx = g.px - width / 2, miny = g.pz - height / 2;
+    minx += a.world_size / 2; miny += a.world_size / 2;
+    minx *= a.texel_x; miny *= a.texel_y;
+    const float maxx = minx + width * a.texel_x, maxy = miny + height * a.texel_y;
+    x0 = (int)floorf(minx); x1 = (int)ceilf(maxx); y0 = (int)floorf(miny); y1 = (int)ceilf(maxy);
+}
+__device__ __forceinline__ int height_byte(const HeightArgs& a, const uint8_t* __restrict__ tex, int i, int j)
+{
+    // GetHeightValue: index = int(x + y * width) in float; clamped where the reference would read out of bounds
+    int index = (int)((float)i + (float)j * (float)a.tex_w);
+    const int n = a.tex_w * a.tex_h;
+    index = index < 0 ? 0 : (index >= n ? n - 1 : index);
+    return tex[index];
+}
+__device__ __forceinline__ float2 finish_minmax(int mnb, int mxb)
+{
+    float mn = mnb <= 255 ? (float)mnb / 255.0f : INFINITY, mx = mxb >= 0 ? (float)mxb / 255.0f : -INFINITY;
+    mn = (mx - mn) == 0.0f ? 0.0f : mn;
+    const float extent = (mx - mn) / 2.0f;
+    return make_float2(mn + extent, extent);          // m_Position.y, m_Extents.y (QuadTree.cpp:197-198)
+}
+__device__ __forceinline__ NodeGeom node_from_index(const HeightArgs& a, uint32_t ix, uint32_t iz, int depth)
+{
+    SelectArgs s;   // only the fields node_from_path reads
+    s.loc[0] = a.loc[0]; s.loc[1] = a.loc[1]; s.loc[2] = a.loc[2]; s.half_w = a.half_w; s.half_h = a.half_h;
+    uint32_t path = 0;
+    for (int l = depth - 1; l >= 0; l--) {
+        const uint32_t bx = (ix >> l) & 1u, bz = (iz >> l) & 1u;
+        path = (path << 2) | (bz ? (bx ? 1u : 0u) : (bx ? 3u : 2u));
+    }
+    return node_from_path(s, path, depth);
+}
+
+// one workgroup per node (large texel rectangles)
+__global__ __launch_bounds__(256) void k_node_heights_block(HeightArgs a, const uint8_t* __restrict__ tex, float2* __restrict__ out)
+{
+    __shared__ int s_mn[4], s_mx[4];
+    const uint32_t n = 1u << a.depth, node = blockIdx.x, ix = node % n, iz = node / n;
+    const NodeGeom g = node_from_index(a, ix, iz, a.depth);
+    int x0, x1, y0, y1; node_texel_rect(a, g, x0, x1, y0, y1);
+    const int w = max(x1 - x0, 0), h = max(y1 - y0, 0);
+    int mn = 256, mx = -1;
+    for (long long k = threadIdx.x; k < (long long)w * h; k += 256) {
+        const int b = height_byte(a, tex, x0 + (int)(k % w), y0 + (int)(k / w));
+        mn = min(mn, b); mx = max(mx, b);
+    }
+    for (int off = 32; off >= 1; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])); mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        const uint32_t base = (uint32_t)((((uint64_t)1 << (2 * a.depth)) - 1) / 3);
+        out[base + node] = finish_minmax(mn, mx);
+    }
+}
+// one lane per node (small rectangles)
+__global__ __launch_bounds__(256) void k_node_heights_thread(HeightArgs a, const uint8_t* __restrict__ tex, float2* __restrict__ out)
+{
+    const uint32_t n = 1u << a.depth;
+    const uint64_t total = (uint64_t)n * n;
+    for (uint64_t node = (uint64_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (uint64_t)gridDim.x * 256) {
+        const uint32_t ix = (uint32_t)(node % n), iz = (uint32_t)(node / n);
+        const NodeGeom g = node_from_index(a, ix, iz, a.depth);
+        int x0, x1, y0, y1; node_texel_rect(a, g, x0, x1, y0, y1);
+        int mn = 256, mx = -1;
+        for (int i = x0; i < x1; i++) for (int j = y0; j < y1; j++) { const int b = height_byte(a, tex, i, j); mn = min(mn, b); mx = max(mx, b); }
+        const uint32_t base = (uint32_t)((((uint64_t)1 << (2 * a.depth)) - 1) / 3);
+        out[base + node] = finish_minmax(mn, mx);
+    }
+}
+
+extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
+{
+    VR_REQUIRE(t != nullptr, "terrain is NULL");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    if (!enable) { t->height_loaded = false; return VR_OK; }
+    const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
+    if (!t->d_node_heights) VR_HIP(hipMalloc(&t->d_node_heights, nodes * sizeof(float2)));
+    HeightArgs a;
+    for (int i = 0; i < 3; i++) a.loc[i] = t->p.location[i];
+    a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f; a.world_size = t->p.world_size;
+    a.texel_x = t->texel_size[0]; a.texel_y = t->texel_size[1]; a.tex_w = t->height.w0; a.tex_h = t->height.h0;
+    VrKernelScope ks(t->ctx, VR_K_NODE_HEIGHTS);
+    for (int d = 0; d <= t->num_lods; d++) {
+        a.depth = d;
+        const uint64_t n = (uint64_t)1 << (2 * d);
+        // texels per node at this depth (approximate; only chooses the kernel)
+        const double per_node = ((double)t->p.surface_size * t->texel_size[0]) * ((double)t->p.surface_size * t->texel_size[1]) / (double)n;
+        if (per_node >= 512.0 && n <= (1u << 20))
+            hipLaunchKernelGGL(k_node_heights_block, dim3((unsigned)n), dim3(256), 0, t->ctx->stream, a, t->d_height, t->d_node_heights);
+        else {
+            const uint64_t blocks = (n + 255) / 256;
+            hipLaunchKernelGGL(k_node_heights_thread, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, t->ctx->stream, a,
+                               t->d_height, t->d_node_heights);
+        }
+    }
+    VR_HIP(hipGetLastError());
+    t->height_loaded = true;
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_download_node_heights(vr_terrain* t, uint32_t first, uint32_t count, float* out)
+{
+    VR_REQUIRE(t && out && t->d_node_heights, "node heights have not been computed");
+    const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
+    VR_REQUIRE((uint64_t)first + count <= nodes, "node id range out of bounds");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    VR_HIP(hipStreamSynchronize(t->ctx->stream));
+    VR_HIP(hipMemcpy(out, t->d_node_heights + first, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost));
     return VR_OK;
 }
 
@@ -196,6 +332,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
     for (int i = 0; i < VR_MAX_LODS; i++) t->lod_ranges[i] = params->min_lod_distance * powf(2.0f, (float)i);
     int l2 = ilog2_floor(params->surface_size);
     t->num_lods = (VR_MAX_LODS - 1) < l2 ? (VR_MAX_LODS - 1) : l2;
+    t->texel_size[0] = (float)hm_w / params->world_size; t->texel_size[1] = (float)hm_h / params->world_size;   // QuadTree.cpp:29
     int rc;
     if ((rc = vr_tex_upload_and_mip(ctx, height_r8, hm_w, hm_h, 1, &t->height, &t->d_height))) { vr_terrain_destroy(t); return rc; }
     if ((rc = vr_tex_upload_and_mip(ctx, albedo, al_w, al_h, 4, &t->albedo, &t->d_albedo))) { vr_terrain_destroy(t); return rc; }
@@ -227,7 +364,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
     (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_ids); (void)hipFree(t->d_instances);
     (void)hipFree(t->d_counters); (void)hipFree(t->d_verts); (void)hipFree(t->d_rect); (void)hipFree(t->d_hard_list);
     (void)hipFree(t->d_hard_tris); (void)hipFree(t->d_hard_first); (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_offset);
-    (void)hipFree(t->d_tile_cursor); (void)hipFree(t->d_bin_entries);
+    (void)hipFree(t->d_tile_cursor); (void)hipFree(t->d_bin_entries); (void)hipFree(t->d_node_heights);
     delete t;
 }
 

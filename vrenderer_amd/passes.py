@@ -227,6 +227,15 @@ class TerrainPass:
                                                    C.byref(lv)), "vr_terrain_download_mip")
         return lv.value
 
+    def SetHeight(self, enable=True):
+        """QuadTree::SetHeight for every node on the device + m_HeightLoaded (QuadTree.cpp:46-51,164-208)."""
+        check(self.ctx.lib.vr_terrain_update_heights(self.handle, int(enable)), "vr_terrain_update_heights")
+
+    def node_heights(self, first, count):
+        out = np.zeros((count, 2), np.float32)
+        check(self.ctx.lib.vr_terrain_download_node_heights(self.handle, first, count, _vp(out)), "vr_terrain_download_node_heights")
+        return out
+
     def NodeSelect(self, view, max_height=400.0):
         """ClearSelectedNodes + NodeSelect + UpdateTransforms (TerrainPass.cpp:173-190).
 
