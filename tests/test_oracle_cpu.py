@@ -304,12 +304,15 @@ def test_set_height_known_answers(oracle, t256):
         base = (4 ** L - 1) // 3
         for (ix, iz) in ((0, 0), (17, 200), (255, 255)):
             py, ey = nh[base + iz * 256 + ix]
-            assert ey == 0.0 and py == 0.0          # single texel: max - min == 0 -> min forced to 0 (QuadTree.cpp:186)
+            # single texel: max - min == 0 -> min forced to 0 (QuadTree.cpp:186), so the box is [0, h]
+            half = (np.float32(h[iz, ix]) / np.float32(255)) / np.float32(2)
+            assert ey == half and py == half
         d = L - 1                                    # 2x2 texel nodes
         b1 = (4 ** d - 1) // 3
         blk = h[0:2, 0:2].astype(np.float32) / np.float32(255)
         e1 = (blk.max() - blk.min()) / np.float32(2)
-        exp_pos = (np.float32(0) if blk.max() == blk.min() else blk.min()) + e1
-        assert nh[b1, 1] == e1 and nh[b1, 0] == exp_pos
+        lo = np.float32(0) if blk.max() == blk.min() else blk.min()
+        e1 = (blk.max() - lo) / np.float32(2)
+        assert nh[b1, 1] == e1 and nh[b1, 0] == lo + e1
     finally:
         t256.set_height(False)
