@@ -243,7 +243,11 @@ typedef struct orc_node {
 struct orc_terrain {
     vr_terrain_params p;
     orc_tex height, albedo;
-    orc_node* root;
+    orc_node* root;               /* first quadtree (== roots[0]) */
+    orc_node* roots[64];          /* one QuadTree per surface (TerrainPass.cpp:97-110) */
+    int num_surfaces;
+    long nodes_per_tree;
+    uint32_t id_offset;           /* while building: surface index * nodes_per_tree */
     long num_nodes;
     int num_lods;
     float lod_ranges[VR_MAX_LODS];
@@ -283,7 +287,7 @@ static void split(orc_terrain* t, orc_node* node, int num_splits, int d, uint32_
     uint32_t base = level_base(cd), n = 1u << cd;
     uint32_t cix[4] = { 2*ix, 2*ix+1, 2*ix, 2*ix+1 }, ciz[4] = { 2*iz+1, 2*iz+1, 2*iz, 2*iz };
     const float* ps[4] = { p0, p1, p2, p3 };
-    for (int i = 0; i < 4; i++) node->child[i] = node_new(ps[i], e, base + ciz[i] * n + cix[i]);
+    for (int i = 0; i < 4; i++) node->child[i] = node_new(ps[i], e, t->id_offset + base + ciz[i] * n + cix[i]);
     t->num_nodes += 4;
     num_splits++;
     if (num_splits <= t->num_lods)
@@ -406,15 +410,28 @@ orc_terrain* orc_terrain_create(const vr_terrain_params* p, const uint8_t* heigh
     t->texel_size[0] = (float)hm_w / p->world_size;
     t->texel_size[1] = (float)hm_h / p->world_size;
     float ext[3] = { p->surface_size / 2.0f, 0.0f, p->surface_size / 2.0f };
-    t->root = node_new(p->location, ext, 0);
-    t->num_nodes = 1;
-    split(t, t->root, 1, 0, 0, 0);
+    /* TerrainPass::Init (TerrainPass.cpp:97-110): WORLD_SIZE / SURFACE_SIZE surfaces per side, one QuadTree each */
+    const int per_side = (int)p->world_size / (int)p->surface_size;
+    t->num_surfaces = per_side * per_side;
+    t->nodes_per_tree = (long)level_base(t->num_lods + 1);
+    t->num_nodes = 0;
+    for (int i = 0; i < t->num_surfaces && i < 64; i++) {
+        int column = i % per_side, row = i / per_side;
+        float x = -0.5f * (float)(per_side - 1) + (float)column, y = -0.5f * (float)(per_side - 1) + (float)row;
+        float loc[3] = { p->location[0] + x * p->surface_size, p->location[1] + 0.0f, p->location[2] + y * p->surface_size };
+        t->id_offset = (uint32_t)((long)i * t->nodes_per_tree);
+        t->roots[i] = node_new(loc, ext, t->id_offset);
+        t->num_nodes += 1;
+        split(t, t->roots[i], 1, 0, 0, 0);
+    }
+    t->root = t->roots[0];
     return t;
 }
 void orc_terrain_destroy(orc_terrain* t)
 {
     if (!t) return;
-    free_tree(t->root); tex_free(&t->height); tex_free(&t->albedo);
+    for (int i = 0; i < t->num_surfaces; i++) free_tree(t->roots[i]);
+    tex_free(&t->height); tex_free(&t->albedo);
     free((void*)t->selected); free(t);
 }
 int  orc_terrain_num_lods(const orc_terrain* t) { return t->num_lods; }
@@ -443,7 +460,8 @@ int orc_select(orc_terrain* t, const vr_view* v, float max_height, int stub_frus
     t->num_selected = 0;                       /* ClearSelectedNodes (TerrainPass.cpp:178) */
     t->stub_frustum = stub_frustum;
     float pos[3] = { v->camera_pos[0], v->camera_pos[1], v->camera_pos[2] };
-    node_select(t, pos, t->root, t->num_lods, v, max_height);   /* TerrainPass.cpp:181 */
+    for (int s = 0; s < t->num_surfaces; s++)                    /* TerrainPass.cpp:176-186: trees in order, shared instance buffer */
+        node_select(t, pos, t->roots[s], t->num_lods, v, max_height);
     t->have_selection = 1;
     for (int i = 0; i < t->num_selected && i < capacity; i++) {
         if (node_ids) node_ids[i] = t->selected[i]->id;
@@ -452,7 +470,7 @@ int orc_select(orc_terrain* t, const vr_view* v, float max_height, int stub_frus
     return t->num_selected;
 }
 
-void orc_set_height(orc_terrain* t) { set_height(t, t->root, 0); }
+void orc_set_height(orc_terrain* t) { for (int s = 0; s < t->num_surfaces; s++) set_height(t, t->roots[s], 0); }
 /* m_HeightLoaded = true is what the reference's (commented-out) async task sets after SetHeight
  * (QuadTree.cpp:46-51); NodeSelect then culls with the node's real y-bounds (:87-91). */
 void orc_set_height_loaded(orc_terrain* t, int loaded) { t->height_loaded = loaded; }
@@ -462,7 +480,7 @@ static void dump_heights(const orc_node* n, float* out, long max_ids)
     if ((long)n->id < max_ids) { out[2 * n->id] = n->pos[1]; out[2 * n->id + 1] = n->ext[1]; }
     for (int i = 0; i < 4; i++) dump_heights(n->child[i], out, max_ids);
 }
-void orc_node_heights(const orc_terrain* t, float* out, long max_ids) { dump_heights(t->root, out, max_ids); }
+void orc_node_heights(const orc_terrain* t, float* out, long max_ids) { for (int s = 0; s < t->num_surfaces; s++) dump_heights(t->roots[s], out, max_ids); }
 int orc_node_height(const orc_terrain* t, uint32_t id, float* py, float* ey)
 {
     /* walk down from the root following the id's (depth, ix, iz) */
@@ -1117,7 +1135,7 @@ double orc_time_select(orc_terrain* t, const vr_view* views, int nv, float max_h
 double orc_time_set_height(orc_terrain* t)
 {
     double t0 = now_s();
-    set_height(t, t->root, 0);
+    orc_set_height(t);
     double t1 = now_s();
     return t1 - t0;
 }

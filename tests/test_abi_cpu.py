@@ -148,3 +148,16 @@ def test_header_is_valid_c(tmp_path):
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o",
                     str(tmp_path / "c_check")], check=True, capture_output=True, text=True)
     assert subprocess.run([str(tmp_path / "c_check")]).returncode == 0
+
+
+def test_png_ingest_round_trip(tmp_path, oracle):
+    """Row f4: PNG heightmap / albedo ingest gives back exactly the bytes TerrainPass.Init takes."""
+    from vrenderer_amd import io as vio
+    h = oracle.synth_heightmap(64)
+    a = oracle.synth_albedo(64, h)
+    vio.save_png(str(tmp_path / "h.png"), h)
+    vio.save_png(str(tmp_path / "a.png"), a)
+    assert np.array_equal(vio.load_heightmap_png(str(tmp_path / "h.png")), h)
+    assert np.array_equal(vio.load_albedo_png(str(tmp_path / "a.png")), a)
+    vio.save_png(str(tmp_path / "rgb.png"), a[..., :3])
+    assert np.array_equal(vio.load_heightmap_png(str(tmp_path / "rgb.png")), a[..., 0])

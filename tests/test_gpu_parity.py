@@ -401,3 +401,39 @@ def test_node_heights_and_height_aware_select(scene_name, request, oracle, gpu_c
     finally:
         ot.set_height(False)
         tp.SetHeight(False)
+
+
+def test_multi_surface_world(oracle, gpu_ctx):
+    """Row f4: WORLD_SIZE / SURFACE_SIZE = 2 -> four quadtrees sharing one instance buffer
+    (TerrainPass.cpp:97-110,175-187), one heightmap over the whole world."""
+    world, surface = 512, 256
+    p = params(surface)
+    p.world_size = float(world)
+    h = oracle.synth_heightmap(world)
+    a = oracle.synth_albedo(world, h)
+    ot = oracle.OracleTerrain(p, h, a)
+    tp = vr.TerrainPass(gpu_ctx, p).Init(h, a)
+    try:
+        assert ot.num_nodes == 4 * 87381 and tp.GetNumLods() == ot.num_lods == 8
+        multi = 0
+        for cam in CAMERAS:
+            eye, tgt = scaled_camera(cam, world)
+            v = vr.make_view(eye, tgt, 1280, 720)
+            n_o, ids_o, inst_o = ot.select(v, 400.0)
+            n_g, ids_g, inst_g = tp.NodeSelect(v, 400.0)
+            assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), cam
+            multi += len(set((ids_o // 87381).tolist())) > 1
+        assert multi > 0, "at least one camera must select nodes from several surfaces"
+        ot.set_height(True)
+        tp.SetHeight(True)
+        assert np.array_equal(tp.node_heights(0, ot.num_nodes).view(np.uint32), ot.node_heights().view(np.uint32))
+        ot.set_height(False)
+        tp.SetHeight(False)
+        sc = dict(ot=ot, tp=tp)
+        eye, tgt = scaled_camera(CAMERAS[1], world)
+        v, gb_o, planes, n_o, n_g = _render_both(sc, oracle, gpu_ctx, eye, tgt, 640, 360)
+        assert n_o == n_g
+        _assert_gbuffer_equal(gb_o, planes, "multi-surface frame")
+    finally:
+        tp.close()
+        ot.close()

@@ -147,6 +147,7 @@ struct vr_terrain {
     float2* d_node_heights = nullptr;
     bool height_loaded = false;
     float texel_size[2] = { 0.0f, 0.0f };   // m_TexelSize (QuadTree.cpp:29)
+    int surfaces_per_side = 1;              // WORLD_SIZE / SURFACE_SIZE (TerrainPass.cpp:97)
 };
 
 // ---- cross-TU entry points ----------------------------------------------------------

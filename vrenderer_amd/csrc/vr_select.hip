@@ -30,14 +30,30 @@ struct SelectArgs {
     int max_instances;
     int height_loaded;           // m_HeightLoaded
     float max_height;
+    // multi-surface worlds (TerrainPass.cpp:97-110): one quadtree per surface
+    int surfaces_per_side, num_surfaces;
+    float surface_size;
+    uint32_t nodes_per_tree;
 };
+
+constexpr int kPathBits = 22;    // 2 bits x 11 levels; frontier entry = surface << 22 | path
+
+// location of surface s (TerrainPass.cpp:102-108): ((-0.5(n-1) + column) * S, 0, (-0.5(n-1) + row) * S)
+__device__ __forceinline__ void surface_location(const SelectArgs& a, int s, float loc[3])
+{
+    const int column = s % a.surfaces_per_side, row = s / a.surfaces_per_side;
+    const float x = -0.5f * (float)(a.surfaces_per_side - 1) + (float)column, y = -0.5f * (float)(a.surfaces_per_side - 1) + (float)row;
+    loc[0] = a.loc[0] + x * a.surface_size; loc[1] = a.loc[1] + 0.0f; loc[2] = a.loc[2] + y * a.surface_size;
+}
 
 struct NodeGeom { float px, pz, ex, ez; uint32_t ix, iz; };
 
 // Replays QuadTree::Split's arithmetic along a path (QuadTree.cpp:212-216).
-__device__ __forceinline__ NodeGeom node_from_path(const SelectArgs& a, uint32_t path, int depth)
+__device__ __forceinline__ NodeGeom node_from_path(const SelectArgs& a, uint32_t path, int depth, int surface = 0)
 {
-    NodeGeom g; g.px = a.loc[0]; g.pz = a.loc[2]; g.ex = a.half_w; g.ez = a.half_h; g.ix = 0; g.iz = 0;
+    float loc[3];
+    surface_location(a, surface, loc);
+    NodeGeom g; g.px = loc[0]; g.pz = loc[2]; g.ex = a.half_w; g.ez = a.half_h; g.ix = 0; g.iz = 0;
     for (int d = depth - 1; d >= 0; d--) {
         uint32_t c = (path >> (2 * d)) & 3u;
         g.ex = g.ex / 2.0f; g.ez = g.ez / 2.0f;
@@ -87,7 +103,8 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     __shared__ uint32_t n_front[2], n_sel, overflow;
     const int tid = threadIdx.x;
     const int L = a.num_lods;
-    if (tid == 0) { frontier[0][0] = 0u; n_front[0] = 1u; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
+    if (tid < a.num_surfaces) frontier[0][tid] = (uint32_t)tid << kPathBits;      // every quadtree's root
+    if (tid == 0) { n_front[0] = (uint32_t)a.num_surfaces; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
     __syncthreads();
 
     int cur = 0;
@@ -95,17 +112,19 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         const int depth = L - lod;
         const uint32_t n = n_front[cur];
         for (uint32_t i = tid; i < n; i += kSelThreads) {
-            uint32_t path = frontier[cur][i];
-            NodeGeom g = node_from_path(a, path, depth);
+            const uint32_t entry = frontier[cur][i];
+            const uint32_t path = entry & ((1u << kPathBits) - 1u);
+            const int surf = (int)(entry >> kPathBits);
+            NodeGeom g = node_from_path(a, path, depth, surf);
             bool select_self = false, expand = false;
             if (!node_in_range(g, a.cam, a.range2[lod])) {
                 // NodeSelect returned false: the parent pushes this child (QuadTree.cpp:120-126);
                 // the root's return value is ignored (TerrainPass.cpp:181).
-                select_self = depth > 0;
+                select_self = depth > 0;    // (a root's return value is ignored for every tree)
             } else {
                 float mny = 0.0f, mxy = a.cam[1];                 // m_HeightLoaded == false (QuadTree.cpp:92-96)
                 if (a.height_loaded) {                            // QuadTree.cpp:87-91
-                    const float2 hy = heights[node_id_of(g, depth)];
+                    const float2 hy = heights[(uint32_t)surf * a.nodes_per_tree + node_id_of(g, depth)];
                     mny = (hy.x - hy.y) * a.max_height; mxy = (hy.x + hy.y) * a.max_height;
                 }
                 if (box_in_frustum(a, g.px - g.ex, mny, g.pz - g.ez, g.px + g.ex, mxy, g.pz + g.ez)) {
@@ -116,14 +135,14 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
             }
             if (select_self) {
                 uint32_t slot = atomicAdd(&n_sel, 1u);
-                if (slot < (uint32_t)kSelectedCap) selected[slot] = ((path << (2 * (L - depth))) << 4) | (uint32_t)depth;
+                if (slot < (uint32_t)kSelectedCap) selected[slot] = ((uint32_t)surf << 26) | ((path << (2 * (L - depth))) << 4) | (uint32_t)depth;
                 else overflow = 1u;
             }
             if (expand) {
                 uint32_t slot = atomicAdd(&n_front[cur ^ 1], 4u);
                 if (slot + 4u <= (uint32_t)kFrontierCap) {
 #pragma unroll
-                    for (uint32_t c = 0; c < 4u; c++) frontier[cur ^ 1][slot + c] = (path << 2) | c;
+                    for (uint32_t c = 0; c < 4u; c++) frontier[cur ^ 1][slot + c] = ((uint32_t)surf << kPathBits) | (path << 2) | c;
                 } else overflow = 1u;
             }
         }
@@ -144,9 +163,10 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         for (uint32_t j = 0; j < total; j++) rank += selected[j] < key ? 1u : 0u;
         if (rank >= limit) continue;
         int depth = (int)(key & 15u);
-        uint32_t path = (key >> 4) >> (2 * (L - depth));
-        NodeGeom g = node_from_path(a, path, depth);
-        const uint32_t id = node_id_of(g, depth);
+        const int surf = (int)(key >> 26);
+        uint32_t path = ((key >> 4) & ((1u << kPathBits) - 1u)) >> (2 * (L - depth));
+        NodeGeom g = node_from_path(a, path, depth, surf);
+        const uint32_t id = (uint32_t)surf * a.nodes_per_tree + node_id_of(g, depth);
         node_ids[rank] = id;
         float py = a.loc[1], ey = 0.0f;
         if (a.height_loaded) { const float2 hy = heights[id]; py = hy.x; ey = hy.y; }
@@ -178,6 +198,9 @@ int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
     a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f;
     a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.max_height = max_height;
     a.height_loaded = (t->height_loaded && t->d_node_heights) ? 1 : 0;
+    a.surfaces_per_side = t->surfaces_per_side; a.num_surfaces = t->surfaces_per_side * t->surfaces_per_side;
+    a.surface_size = t->p.surface_size;
+    a.nodes_per_tree = (uint32_t)((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
     VrKernelScope ks(t->ctx, VR_K_SELECT);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters,
                        (const float2*)t->d_node_heights);
@@ -219,8 +242,9 @@ __device__ __forceinline__ float2 finish_minmax(int mnb, int mxb)
 }
 __device__ __forceinline__ NodeGeom node_from_index(const HeightArgs& a, uint32_t ix, uint32_t iz, int depth)
 {
-    SelectArgs s;   // only the fields node_from_path reads
+    SelectArgs s;   // only the fields node_from_path reads; a.loc is already the surface's location
     s.loc[0] = a.loc[0]; s.loc[1] = a.loc[1]; s.loc[2] = a.loc[2]; s.half_w = a.half_w; s.half_h = a.half_h;
+    s.surfaces_per_side = 1; s.surface_size = 0.0f;
     uint32_t path = 0;
     for (int l = depth - 1; l >= 0; l--) {
         const uint32_t bx = (ix >> l) & 1u, bz = (iz >> l) & 1u;
@@ -273,24 +297,32 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
     VR_HIP(hipSetDevice(t->ctx->device));
     if (!enable) { t->height_loaded = false; return VR_OK; }
     const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
-    if (!t->d_node_heights) VR_HIP(hipMalloc(&t->d_node_heights, nodes * sizeof(float2)));
+    const int num_surfaces = t->surfaces_per_side * t->surfaces_per_side;
+    if (!t->d_node_heights) VR_HIP(hipMalloc(&t->d_node_heights, nodes * num_surfaces * sizeof(float2)));
     HeightArgs a;
-    for (int i = 0; i < 3; i++) a.loc[i] = t->p.location[i];
     a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f; a.world_size = t->p.world_size;
     a.texel_x = t->texel_size[0]; a.texel_y = t->texel_size[1]; a.tex_w = t->height.w0; a.tex_h = t->height.h0;
     VrKernelScope ks(t->ctx, VR_K_NODE_HEIGHTS);
+    for (int surf = 0; surf < num_surfaces; surf++) {
+    {   // TerrainPass.cpp:102-108
+        const int column = surf % t->surfaces_per_side, row = surf / t->surfaces_per_side;
+        const float x = -0.5f * (float)(t->surfaces_per_side - 1) + (float)column, y = -0.5f * (float)(t->surfaces_per_side - 1) + (float)row;
+        a.loc[0] = t->p.location[0] + x * t->p.surface_size; a.loc[1] = t->p.location[1] + 0.0f; a.loc[2] = t->p.location[2] + y * t->p.surface_size;
+    }
+    float2* out = t->d_node_heights + (size_t)surf * nodes;
     for (int d = 0; d <= t->num_lods; d++) {
         a.depth = d;
         const uint64_t n = (uint64_t)1 << (2 * d);
         // texels per node at this depth (approximate; only chooses the kernel)
         const double per_node = ((double)t->p.surface_size * t->texel_size[0]) * ((double)t->p.surface_size * t->texel_size[1]) / (double)n;
         if (per_node >= 512.0 && n <= (1u << 20))
-            hipLaunchKernelGGL(k_node_heights_block, dim3((unsigned)n), dim3(256), 0, t->ctx->stream, a, t->d_height, t->d_node_heights);
+            hipLaunchKernelGGL(k_node_heights_block, dim3((unsigned)n), dim3(256), 0, t->ctx->stream, a, t->d_height, out);
         else {
             const uint64_t blocks = (n + 255) / 256;
             hipLaunchKernelGGL(k_node_heights_thread, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, t->ctx->stream, a,
-                               t->d_height, t->d_node_heights);
+                               t->d_height, out);
         }
+    }
     }
     VR_HIP(hipGetLastError());
     t->height_loaded = true;
@@ -300,7 +332,7 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
 extern "C" VR_API int vr_terrain_download_node_heights(vr_terrain* t, uint32_t first, uint32_t count, float* out)
 {
     VR_REQUIRE(t && out && t->d_node_heights, "node heights have not been computed");
-    const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
+    const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3) * (uint64_t)(t->surfaces_per_side * t->surfaces_per_side);
     VR_REQUIRE((uint64_t)first + count <= nodes, "node id range out of bounds");
     VR_HIP(hipSetDevice(t->ctx->device));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
@@ -324,10 +356,15 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
     VR_REQUIRE(params->grid_size == kGrid, "grid_size must be 32");
     VR_REQUIRE(params->max_instances > 0 && params->max_instances <= 4096, "max_instances must be in 1..4096");
     VR_REQUIRE(params->surface_size >= 1.0f && params->world_size >= params->surface_size, "bad surface/world size");
+    // static_assert(WORLD_SIZE >= SURFACE_SIZE && WORLD_SIZE % SURFACE_SIZE == 0) (TerrainPass.h:30)
+    const int per_side = (int)params->world_size / (int)params->surface_size;
+    VR_REQUIRE((float)((int)params->world_size) == params->world_size && (float)((int)params->surface_size) == params->surface_size
+               && (int)params->world_size % (int)params->surface_size == 0, "world_size must be an integer multiple of surface_size");
+    VR_REQUIRE(per_side * per_side <= 64, "at most 64 surfaces");
     VR_REQUIRE(params->min_lod_distance > 0.0f && params->morph_start > 0.0f && params->morph_start < 1.0f, "bad LOD parameters");
     VR_HIP(hipSetDevice(ctx->device));
     vr_terrain* t = new vr_terrain();
-    t->ctx = ctx; t->p = *params;
+    t->ctx = ctx; t->p = *params; t->surfaces_per_side = per_side;
     // QuadTree::InitLodRanges (QuadTree.cpp:234-241), QuadTree::Init numLods (QuadTree.cpp:22)
     for (int i = 0; i < VR_MAX_LODS; i++) t->lod_ranges[i] = params->min_lod_distance * powf(2.0f, (float)i);
     int l2 = ilog2_floor(params->surface_size);
