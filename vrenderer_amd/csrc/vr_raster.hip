@@ -230,16 +230,53 @@ __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1
     return (uint64_t)(uint32_t)tx0 | ((uint64_t)(uint32_t)ty0 << 16) | ((uint64_t)(uint32_t)tx1 << 32) | ((uint64_t)(uint32_t)ty1 << 48);
 }
 
-__device__ __forceinline__ uint64_t bin_count_triangle(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2,
-                                                        uint32_t* __restrict__ tile_count)
+// raster-tile rectangle a triangle touches, or ~0 when it is culled
+__device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2)
 {
     TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
     if (!t.visible) return ~0ull;
-    const int tx0 = t.x0 / kRasterTile, tx1 = t.x1 / kRasterTile, ty0 = t.y0 / kRasterTile, ty1 = t.y1 / kRasterTile;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++)
-            if (tile_owned(a, tx, ty)) atomicAdd(&tile_count[ty * a.rtx + tx], 1u);
-    return pack_rect(tx0, ty0, tx1, ty1);
+    return pack_rect(t.x0 / kRasterTile, t.y0 / kRasterTile, t.x1 / kRasterTile, t.y1 / kRasterTile);
+}
+
+// Adds `r`'s triangle to the per-tile counters (FILL = false) or claims its bin slots and writes
+// `entry` (FILL = true).  Neighbouring triangles of a terrain tile mostly land in the same raster
+// tile, so the common single-tile case is aggregated per wave: lanes that target the same tile elect
+// a leader (ballot + readlane), which issues ONE atomic for all of them.  Must be called by every
+// lane that is still in the caller's loop (wave-level operations inside).
+template <bool FILL>
+__device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32_t entry, uint32_t* __restrict__ counters_or_cursor,
+                                         uint32_t* __restrict__ entries)
+{
+    const int tx0 = (int)(r & 0xffffu), ty0 = (int)((r >> 16) & 0xffffu), tx1 = (int)((r >> 32) & 0xffffu), ty1 = (int)((r >> 48) & 0xffffu);
+    const bool live = r != ~0ull;
+    const bool single = live && tx0 == tx1 && ty0 == ty1;
+    const int tile = (single && tile_owned(a, tx0, ty0)) ? ty0 * a.rtx + tx0 : -1;
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long todo = __ballot(tile >= 0);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int t = __builtin_amdgcn_readlane(tile, lead);
+        const unsigned long long same = __ballot(tile == t);
+        const uint32_t n = (uint32_t)__popcll(same);
+        uint32_t base = 0;
+        if (lane == lead) base = atomicAdd(&counters_or_cursor[t], n);
+        if (FILL) {
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+            if (tile == t) {
+                const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                if (pos < a.bin_capacity) entries[pos] = entry;
+            }
+        }
+        todo &= ~same;
+    }
+    if (live && !single) {
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++)
+                if (tile_owned(a, tx, ty)) {
+                    const uint32_t pos = atomicAdd(&counters_or_cursor[ty * a.rtx + tx], 1u);
+                    if (FILL && pos < a.bin_capacity) entries[pos] = entry;
+                }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -274,9 +311,10 @@ __global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __re
                 const uint32_t slot = atomicAdd(&counters[C_HARDLIST], 1u);
                 if (slot < a.hard_cap) hard_list[slot] = tri; else atomicOr(&counters[C_FLAGS], 2u);
             } else {
-                r = bin_count_triangle(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), tile_count);
+                r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2));
             }
         }
+        bin_rect<false>(a, r, 0u, tile_count, nullptr);
         rect[tri] = r;
     }
 }
@@ -369,7 +407,13 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
             HardTriRec rec;
             rec.v0 = a.extra_vert_base + vbase; rec.v1 = rec.v0 + s + 1; rec.v2 = rec.v0 + s + 2;
             rec.order_key = (tri << 4) | (s << 1) | 1u;
-            const uint64_t r = bin_count_triangle(a, load_sv(verts, rec.v0), load_sv(verts, rec.v1), load_sv(verts, rec.v2), tile_count);
+            const uint64_t r = triangle_rect(a, load_sv(verts, rec.v0), load_sv(verts, rec.v1), load_sv(verts, rec.v2));
+            if (r != ~0ull) {       // rare path, divergent loop: plain per-tile atomics
+                const int qx0 = (int)(r & 0xffffu), qy0 = (int)((r >> 16) & 0xffffu), qx1 = (int)((r >> 32) & 0xffffu), qy1 = (int)((r >> 48) & 0xffffu);
+                for (int ty = qy0; ty <= qy1; ty++)
+                    for (int tx = qx0; tx <= qx1; tx++)
+                        if (tile_owned(a, tx, ty)) atomicAdd(&tile_count[ty * a.rtx + tx], 1u);
+            }
             rec.rect_lo = (uint32_t)r; rec.rect_hi = (uint32_t)(r >> 32); rec.pad0 = 0; rec.pad1 = 0;
             hard_tris[tbase + s] = rec;
         }
@@ -407,18 +451,6 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, const uint32_t* __re
 // ---------------------------------------------------------------------------------------
 // k_fill: write bin entries.  Entry = draw-order key: (triangle id << 4) | (sub << 1) | hard.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void fill_rect(const RasterArgs& a, uint64_t r, uint32_t entry, uint32_t* __restrict__ tile_cursor,
-                                          uint32_t* __restrict__ entries)
-{
-    const int tx0 = (int)(r & 0xffffu), ty0 = (int)((r >> 16) & 0xffffu), tx1 = (int)((r >> 32) & 0xffffu), ty1 = (int)((r >> 48) & 0xffffu);
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++)
-            if (tile_owned(a, tx, ty)) {
-                const uint32_t pos = atomicAdd(&tile_cursor[ty * a.rtx + tx], 1u);
-                if (pos < a.bin_capacity) entries[pos] = entry;
-            }
-}
-
 __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __restrict__ counters, const uint64_t* __restrict__ rect,
                                                const HardTriRec* __restrict__ hard_tris, uint32_t* __restrict__ tile_cursor,
                                                uint32_t* __restrict__ entries)
@@ -426,14 +458,13 @@ __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __re
     const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     const uint32_t n_hard = min(counters[C_HARDTRIS], a.hard_cap * 4u);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reg + n_hard; i += gridDim.x * blockDim.x) {
-        if (i < n_reg) {
-            const uint64_t r = rect[i];
-            if (r != ~0ull) fill_rect(a, r, i << 4, tile_cursor, entries);
-        } else {
+        uint64_t r; uint32_t entry;
+        if (i < n_reg) { r = rect[i]; entry = i << 4; }
+        else {
             const HardTriRec rec = hard_tris[i - n_reg];
-            const uint64_t r = (uint64_t)rec.rect_lo | ((uint64_t)rec.rect_hi << 32);
-            if (r != ~0ull) fill_rect(a, r, rec.order_key, tile_cursor, entries);
+            r = (uint64_t)rec.rect_lo | ((uint64_t)rec.rect_hi << 32); entry = rec.order_key;
         }
+        bin_rect<true>(a, r, entry, tile_cursor, entries);
     }
 }
 
