@@ -89,8 +89,10 @@ __device__ __forceinline__ void snap_vertex(DevVert& v, float vp_x, float vp_y, 
 }
 
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const vr_instance* __restrict__ inst,
-                                                 const uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
+                                                 uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
 {
+    // first kernel of every frame: reset the frame's work counters (k_setup is the first to use them)
+    if (blockIdx.x == 0 && threadIdx.x < 6) counters[2 + threadIdx.x] = 0u;
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels];
     r8[threadIdx.x] = (float)threadIdx.x / 255.0f;     // UNORM8 -> float, correctly rounded
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 // ---------------------------------------------------------------------------------------
 // k_scan: exclusive prefix sum of the per-tile counts (one workgroup)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(int n_tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+__global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity)
 {
     __shared__ uint32_t partial[1024];
@@ -441,7 +443,9 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, const uint32_t* __re
         __syncthreads();
     }
     uint32_t run = partial[tid] - s;
-    for (int i = b; i < e; i++) { tile_offset[i] = run; tile_cursor[i] = run; run += tile_count[i]; }
+    // the counts are consumed here: zero them for the next frame (saves a memset per frame); the
+    // rasteriser gets a bin's length from cursor - offset once k_fill has run
+    for (int i = b; i < e; i++) { tile_offset[i] = run; tile_cursor[i] = run; run += tile_count[i]; tile_count[i] = 0u; }
     if (tid == 1023) {
         counters[C_BINTOTAL] = partial[1023];
         if (partial[1023] > capacity) atomicOr(&counters[C_FLAGS], 2u);
@@ -664,7 +668,7 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
 
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
-                                                 const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
+                                                 const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
                                                  const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     }
     __syncthreads();
 
-    const uint32_t n = tile_count[tile], off = tile_offset[tile];
+    const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
     const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + kRasterTile - 1, a.vx1), by1 = min(oy + kRasterTile - 1, a.vy1);
     const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
     for (uint32_t base = 0; base < n; base += 256) {
@@ -882,10 +886,11 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         VR_HIP(hipMalloc(&t->d_tile_count, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&t->d_tile_offset, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&t->d_tile_cursor, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMemsetAsync(t->d_tile_count, 0, sizeof(uint32_t) * n_tiles, s));   // k_scan re-zeroes it every frame
+        VR_HIP(hipMemsetAsync(t->d_tile_cursor, 0, sizeof(uint32_t) * n_tiles, s));
+        VR_HIP(hipMemsetAsync(t->d_tile_offset, 0, sizeof(uint32_t) * n_tiles, s));
         t->scratch_tiles = n_tiles;
     }
-    VR_HIP(hipMemsetAsync(t->d_tile_count, 0, sizeof(uint32_t) * n_tiles, s));
-    VR_HIP(hipMemsetAsync(t->d_counters + 2, 0, sizeof(uint32_t) * 6, s));
 
     VertexArgs va;
     for (int i = 0; i < 16; i++) { va.w2v[i] = view->world_to_view[i]; va.v2c[i] = view->view_to_clip[i]; }
@@ -912,7 +917,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER);
         hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, t->d_verts, hard_tris, t->d_hard_first,
-                           t->d_tile_count, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
+                           t->d_tile_cursor, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
     VR_HIP(hipGetLastError());

@@ -475,10 +475,11 @@ extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
     VR_HIP(hipMemcpy(out, t->d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     out[6] = 0; out[7] = 0;
-    if (t->scratch_tiles > 0 && t->d_tile_count) {
-        std::vector<uint32_t> c((size_t)t->scratch_tiles);
-        VR_HIP(hipMemcpy(c.data(), t->d_tile_count, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint32_t v : c) { if (v > out[6]) out[6] = v; if (v) out[7]++; }
+    if (t->scratch_tiles > 0 && t->d_tile_cursor) {
+        std::vector<uint32_t> c((size_t)t->scratch_tiles), o((size_t)t->scratch_tiles);
+        VR_HIP(hipMemcpy(c.data(), t->d_tile_cursor, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        VR_HIP(hipMemcpy(o.data(), t->d_tile_offset, o.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < c.size(); i++) { const uint32_t v = c[i] - o[i]; if (v > out[6]) out[6] = v; if (v) out[7]++; }
     }
     return VR_OK;
 }
