@@ -307,16 +307,18 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
 }
 
 // ---- tiled deferred lighting for many point lights (BASELINE config 5) ---------------------------
-// One workgroup = one 16x16 pixel tile, one lane = one pixel.  Phases:
-//   1. decode the surface, reduce the world-space bounding box of the tile's covered pixels
-//      (wave shuffles, then 4 partial boxes through LDS);
+// One workgroup = one 32x32 pixel tile, one lane = 4 horizontally adjacent pixels (16-byte loads and
+// stores, as in k_deferred).  Phases:
+//   1. load the lane's 4 pixels, reconstruct their world positions and reduce the world-space
+//      bounding box of the tile's covered pixels (wave shuffles, then 4 partial boxes through LDS);
 //   2. cull: lane t tests light c*256+t (sphere = position/range vs the tile box; directional lights
 //      always pass); survivors are appended to an LDS list in light order with a wave ballot + popcount
 //      prefix, and their constants are staged in LDS (48 B each);
-//   3. shade: every lane walks the tile's list (LDS broadcast reads) with the same BRDF as k_deferred.
+//   3. shade: the lane walks the tile's list once per pixel (LDS broadcast reads) with the same BRDF
+//      as k_deferred.
 // A light culled here has zero attenuation for every pixel of the tile, so the sum equals the
 // all-lights loop of the oracle.
-constexpr int kLightTile = 16;
+constexpr int kLightTile = 32;
 constexpr int kTileLightCap = 1024;
 struct TiledLight { float vec[3]; float inv_range; float color[3]; float intensity; float cosH, sinH, tanH; int type; };
 
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
                                                          const float* __restrict__ lut_g, const int32_t* __restrict__ owned_tiles,
                                                          uint32_t* __restrict__ overflow_flag)
 {
+#pragma clang fp contract(fast)
     __shared__ float lut[256];
     __shared__ TiledLight s_light[kTileLightCap];
     __shared__ float s_box[4][6];
@@ -337,39 +340,55 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
     lut[tid] = lut_g[tid];
     if (tid == 0) s_count = 0u;
 
-    int px, py; size_t out_index;
-    const int lx = tid & 15, ly = tid >> 4;
+    int px0, py; size_t out_index;
+    const int lx = (tid & 7) * 4, ly = tid >> 3;                     // 8 lanes x 4 px per row, 32 rows
     if (PACKED) {
-        const int sub = VR_OWNER_TILE / kLightTile;                  // 8 light tiles per owner-tile side
+        const int sub = VR_OWNER_TILE / kLightTile;                  // 4 light tiles per owner-tile side
         const int lt = blockIdx.x / (sub * sub), st = blockIdx.x - lt * (sub * sub);
         const int tile = owned_tiles[lt];
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int ox = (st % sub) * kLightTile + lx, oy = (st / sub) * kLightTile + ly;
-        px = tx * VR_OWNER_TILE + ox; py = ty * VR_OWNER_TILE + oy;
+        px0 = tx * VR_OWNER_TILE + ox; py = ty * VR_OWNER_TILE + oy;
         out_index = ((size_t)lt * VR_OWNER_TILE + oy) * VR_OWNER_TILE + ox;
     } else {
         const int tiles_x = (a.w + kLightTile - 1) / kLightTile;
         const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-        px = tx * kLightTile + lx; py = ty * kLightTile + ly;
-        out_index = (size_t)py * a.w + px;
+        px0 = tx * kLightTile + lx; py = ty * kLightTile + ly;
+        out_index = (size_t)py * a.w + px0;
     }
-    const bool inside = px < a.w && py < a.h;
+    const bool inside = px0 < a.w && py < a.h;                       // the frame width is a multiple of 4
     __syncthreads();
 
-    Surface s;
-    bool covered = false;
+    float depth[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+    uint32_t dfa[4] = { 0, 0, 0, 0 }, spa[4] = { 0, 0, 0, 0 }, na[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ea[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (inside) {
-        const size_t p = (size_t)py * a.w + px;
-        const float depth = g_depth[p];
-        const uint2 n = g_nrm[p], e = g_emi[p];
-        s = decode_surface(a, lut, px, py, depth, g_diff[p], g_spec[p], n.x, n.y, e.x, e.y);
-        covered = depth < 1.0f;                                      // background pixels receive no light (albedo = F0 = N = 0)
+        const size_t p = (size_t)py * a.w + px0;
+        const float4 dz = *reinterpret_cast<const float4*>(g_depth + p);
+        const uint4 df = *reinterpret_cast<const uint4*>(g_diff + p);
+        const uint4 sp = *reinterpret_cast<const uint4*>(g_spec + p);
+        const uint4 n0 = *reinterpret_cast<const uint4*>(g_nrm + p);
+        const uint4 n1 = *reinterpret_cast<const uint4*>(g_nrm + p + 2);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(g_emi + p);
+        const uint4 e1 = *reinterpret_cast<const uint4*>(g_emi + p + 2);
+        depth[0] = dz.x; depth[1] = dz.y; depth[2] = dz.z; depth[3] = dz.w;
+        dfa[0] = df.x; dfa[1] = df.y; dfa[2] = df.z; dfa[3] = df.w; spa[0] = sp.x; spa[1] = sp.y; spa[2] = sp.z; spa[3] = sp.w;
+        na[0] = n0.x; na[1] = n0.y; na[2] = n0.z; na[3] = n0.w; na[4] = n1.x; na[5] = n1.y; na[6] = n1.z; na[7] = n1.w;
+        ea[0] = e0.x; ea[1] = e0.y; ea[2] = e0.z; ea[3] = e0.w; ea[4] = e1.x; ea[5] = e1.y; ea[6] = e1.z; ea[7] = e1.w;
     }
-    // ---- 1. tile bounding box in world space
+    // ---- 1. tile bounding box in world space (background pixels receive no light: albedo = F0 = N = 0)
     const float big = 3.0e38f;
-    float lo[3], hi[3];
+    float lo[3] = { big, big, big }, hi[3] = { -big, -big, -big };
 #pragma unroll
-    for (int c = 0; c < 3; c++) { lo[c] = covered ? s.wp[c] : big; hi[c] = covered ? s.wp[c] : -big; }
+    for (int k = 0; k < 4; k++) {
+        if (!(inside && depth[k] < 1.0f)) continue;
+        const float cx = ((float)(px0 + k) + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+        float w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth[k] * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
+        const float rw = fast_rcp(w4[3]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float v = w4[c] * rw; lo[c] = vr_min(lo[c], v); hi[c] = vr_max(hi[c], v); }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
@@ -383,6 +402,9 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
         hi[c] = vr_max(vr_max(s_box[0][3 + c], s_box[1][3 + c]), vr_max(s_box[2][3 + c], s_box[3][3 + c]));
     }
     const bool any_covered = lo[0] <= hi[0];
+    // reconstruction here and in decode_surface may differ in the last bit: pad the box
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float pad = 1e-4f * vr_max(fabsf(lo[c]), fabsf(hi[c])) + 1e-6f; lo[c] -= pad; hi[c] += pad; }
 
     // ---- 2. cull, 256 lights per round, list kept in light order
     for (int base = 0; base < num_lights && any_covered; base += 256) {
@@ -424,17 +446,26 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
 
     // ---- 3. shade
     if (!inside) return;
-    float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
-    if (covered) {
-        const uint32_t n = s_count;
-        for (uint32_t i = 0; i < n; i++) {
-            const TiledLight& t = s_light[i];
-            add_light(s, t.type, t.vec, t.inv_range, t.color, t.intensity, t.cosH, t.sinH, t.tanH, diffuseTerm, specularTerm);
+    const uint32_t n = s_count;
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const Surface s = decode_surface(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1]);
+        float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
+        if (depth[k] < 1.0f) {
+            for (uint32_t i = 0; i < n; i++) {
+                const TiledLight& t = s_light[i];
+                add_light(s, t.type, t.vec, t.inv_range, t.color, t.intensity, t.cosH, t.sinH, t.tanH, diffuseTerm, specularTerm);
+            }
         }
+        float rgb[3];
+        finish_pixel(a, s, diffuseTerm, specularTerm, rgb);
+        o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
+        o[2 * k + 1] = vr_float_to_half(rgb[2]);
     }
-    float rgb[3];
-    finish_pixel(a, s, diffuseTerm, specularTerm, rgb);
-    out[out_index] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
+    uint4* dst = reinterpret_cast<uint4*>(out + out_index);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
@@ -463,6 +494,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
     a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h; a.num_lights = 0;
     const bool packed = part != nullptr;
+    VR_REQUIRE(gb->w % 4 == 0, "the tiled pass needs a frame width that is a multiple of 4");
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
     if (packed) {
         int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
