@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--size", type=int, default=2048, help="heightmap / world size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="do not build frame i+1's geometry ahead (vr_terrain_prepare) under frame i's tile pass")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: run the all-gather + de-tile of frame i on the render stream instead of overlapping it with frame i+1")
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
@@ -171,14 +173,18 @@ def main():
     views = [vr.make_view(*camera(i), W, H) for i in range(120)]
 
     def step(i):
-        v = views[i % 120]
+        v, vnext = views[i % 120], views[(i + 1) % 120]
         if not use_dist:
             tp.Render(v, v, rt, rp, None)
+            if not args.no_prepare:
+                tp.Prepare(vnext, rt, rp, None)      # frame i+1's geometry is built under frame i's tile pass
             deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, None)
             return
         b = i % nbuf
         main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
         tp.Render(v, v, rt, rp, part)
+        if not args.no_prepare:
+            tp.Prepare(vnext, rt, rp, part)
         deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_bufs[b], part)
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):

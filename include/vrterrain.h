@@ -142,6 +142,12 @@ VR_API int  vr_context_create(int device_ordinal, vr_context** out);
 VR_API void vr_context_destroy(vr_context* ctx);
 VR_API int  vr_context_set_stream(vr_context* ctx, void* hip_stream);
 VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submit + wait */
+/* Options.  VR_OPT_ASYNC_GEOMETRY (default 1): vr_terrain_render runs its view-dependent geometry
+ * stages (select, vertex, setup, bins) on a second stream, so that they overlap whatever the caller
+ * queued on the context's stream after the previous vr_terrain_render (typically vr_deferred_light
+ * of the previous frame); the tile pass stays on the context's stream.  0 = everything on one stream. */
+enum { VR_OPT_ASYNC_GEOMETRY = 1 };
+VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);
 
@@ -203,6 +209,13 @@ VR_API int  vr_terrain_select(vr_terrain* t, const vr_view* view, float max_heig
 VR_API int  vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev,
                               vr_gbuffer* gb, const vr_render_params* rp,
                               const vr_partition* part);
+/* Optional: build the view-dependent geometry (select .. bins) of an upcoming vr_terrain_render ahead of
+ * time, on the terrain's geometry stream.  Called right after vr_terrain_render of frame N with frame
+ * N+1's view, it overlaps frame N's tile pass (and leaves its lighting pass alone).  The next
+ * vr_terrain_render uses it when view, max_height, target size and partition are identical; otherwise
+ * it is discarded.  Extension; the reference has no counterpart (its frames are strictly serial). */
+VR_API int  vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp,
+                               const vr_partition* part);
 /* EditorParams::m_NumChunks of the last render/select (syncs the stream). */
 VR_API int  vr_terrain_num_chunks(vr_terrain* t, uint32_t* count);
 

@@ -21,6 +21,7 @@ VR_LIGHT_DIRECTIONAL = 1
 VR_LIGHT_SPOT = 2
 VR_LIGHT_POINT = 3
 VR_K_COUNT = 12
+VR_OPT_ASYNC_GEOMETRY = 1
 
 
 class TerrainParams(C.Structure):
@@ -107,10 +108,10 @@ LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvrterrain.so")
 
 # every symbol include/vrterrain.h declares
 EXPORTS = [
-    "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_synchronize",
+    "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_set_option", "vr_context_synchronize",
     "vr_last_error", "vr_version", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
-    "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_num_chunks",
+    "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_prepare", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_partition_num_tiles",
@@ -144,6 +145,7 @@ def load_library():
         "vr_context_create": (C.c_int, [C.c_int, P(vp)]),
         "vr_context_destroy": (None, [vp]),
         "vr_context_set_stream": (C.c_int, [vp, vp]),
+        "vr_context_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
         "vr_context_synchronize": (C.c_int, [vp]),
         "vr_last_error": (C.c_char_p, []),
         "vr_version": (C.c_char_p, []),
@@ -165,6 +167,7 @@ def load_library():
         "vr_terrain_download_node_heights": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "vr_terrain_select": (C.c_int, [vp, P(View), C.c_float, vp, vp, P(C.c_uint32)]),
         "vr_terrain_render": (C.c_int, [vp, P(View), P(View), vp, P(RenderParams), P(Partition)]),
+        "vr_terrain_prepare": (C.c_int, [vp, P(View), vp, P(RenderParams), P(Partition)]),
         "vr_terrain_num_chunks": (C.c_int, [vp, P(C.c_uint32)]),
         "vr_gbuffer_create": (C.c_int, [vp, C.c_int32, C.c_int32, P(vp)]),
         "vr_gbuffer_destroy": (None, [vp]),

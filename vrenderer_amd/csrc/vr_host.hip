@@ -76,6 +76,14 @@ extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
     return VR_OK;
 }
 
+extern "C" VR_API int vr_context_set_option(vr_context* c, int option, int value)
+{
+    VR_REQUIRE(c != nullptr, "ctx is NULL");
+    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY, "unknown option");
+    c->async_geometry = value != 0;
+    return VR_OK;
+}
+
 extern "C" VR_API int vr_context_synchronize(vr_context* c)
 {
     VR_REQUIRE(c != nullptr, "ctx is NULL");
@@ -91,15 +99,16 @@ static hipEvent_t take_event(vr_context* c)
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-VrKernelScope::VrKernelScope(vr_context* ctx, int id) : c(ctx)
+VrKernelScope::VrKernelScope(vr_context* ctx, int id) : VrKernelScope(ctx, id, ctx->stream) {}
+VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream) : c(ctx), st(stream)
 {
     if (!c->timing) return;
     hipEvent_t e0 = take_event(c); e1 = take_event(c);
     if (!e0 || !e1) { e1 = nullptr; return; }
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, st);
     c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
 }
-VrKernelScope::~VrKernelScope() { if (e1) (void)hipEventRecord(e1, c->stream); }
+VrKernelScope::~VrKernelScope() { if (e1) (void)hipEventRecord(e1, st); }
 
 static void timing_reset(vr_context* c)
 {
@@ -124,6 +133,7 @@ extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT],
     for (int i = 0; i < VR_K_COUNT; i++) { ms_sum[i] = 0.0f; launches[i] = 0; }
     for (size_t i = 0; i < c->ev_id.size(); i++) {
         float ms = 0.0f;
+        VR_HIP(hipEventSynchronize(c->ev_end[i]));      // may have been recorded on a terrain's geometry stream
         VR_HIP(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
         ms_sum[c->ev_id[i]] += ms; launches[c->ev_id[i]]++;
     }

@@ -87,6 +87,7 @@ struct vr_context {
     int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
     int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64) inside owned owner tiles
     int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+    bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
     // light list of vr_deferred_light_tiled
     DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights;
     uint32_t* d_flags = nullptr;
@@ -99,8 +100,9 @@ struct vr_context {
 
 // Records a begin/end event pair around one kernel launch when timing is enabled.
 struct VrKernelScope {
-    vr_context* c; hipEvent_t e1 = nullptr;
-    VrKernelScope(vr_context* ctx, int id);
+    vr_context* c; hipEvent_t e1 = nullptr; hipStream_t st = nullptr;
+    VrKernelScope(vr_context* ctx, int id);                       // on the context's stream
+    VrKernelScope(vr_context* ctx, int id, hipStream_t stream);   // on another stream of the same device
     ~VrKernelScope();
 };
 
@@ -118,6 +120,29 @@ struct vr_image {
     size_t capacity_bytes;
 };
 
+// Everything one frame's geometry stages produce and its tile pass consumes.  Two sets alternate so
+// that the geometry of frame N+1 can be built while the tile pass of frame N still reads its own.
+struct GeoSet {
+    uint32_t* d_node_ids = nullptr;      // select outputs
+    vr_instance* d_instances = nullptr;
+    uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
+    DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
+    uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled
+    uint32_t* d_hard_list = nullptr;     // triangle ids that need the clipper
+    HardTriRec* d_hard_tris = nullptr;   // capacity hard_cap * 4
+    uint32_t* d_hard_first = nullptr;    // per regular triangle id: first HardTriRec index
+    uint32_t* d_tile_count = nullptr;    // per raster tile
+    uint32_t* d_tile_offset = nullptr;
+    uint32_t* d_tile_cursor = nullptr;
+    uint32_t* d_bin_entries = nullptr;
+    int scratch_tiles = 0;
+    hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
+    bool raster_recorded = false, have_selection = false;
+    // vr_terrain_prepare: geometry already built for exactly these inputs
+    bool prepared = false;
+    vr_view prep_view; vr_render_params prep_rp; int prep_w = 0, prep_h = 0, prep_rank = 0, prep_world = 0;
+};
+
 struct vr_terrain {
     vr_context* ctx;
     vr_terrain_params p;
@@ -125,35 +150,27 @@ struct vr_terrain {
     float lod_ranges[VR_MAX_LODS];
     DevTex height, albedo;
     uint8_t* d_height = nullptr; uint8_t* d_albedo = nullptr;
-    // select outputs (device)
-    uint32_t* d_node_ids = nullptr;
-    vr_instance* d_instances = nullptr;
-    uint32_t* d_counters = nullptr;     // [0] selected count, [1] status flags, [2] hard tris, [3] hard verts, ...
-    // raster scratch (device), sized for max_instances
-    DevVert* d_verts = nullptr;         // max_instances*1089 regular + extra (clipper) region
     uint32_t extra_vert_cap = 0, hard_cap = 0;
-    uint64_t* d_rect = nullptr;         // per triangle: tile rect or ~0 when culled
-    uint32_t* d_hard_list = nullptr;    // triangle ids that need the clipper
-    HardTriRec* d_hard_tris = nullptr;  // capacity hard_cap * 4
-    uint32_t* d_hard_first = nullptr;   // per regular triangle id: first HardTri index
-    uint32_t* d_tile_count = nullptr;   // per raster tile
-    uint32_t* d_tile_offset = nullptr;
-    uint32_t* d_tile_cursor = nullptr;
-    uint32_t* d_bin_entries = nullptr;
     size_t bin_capacity = 0;
-    int scratch_tiles = 0;
-    bool have_selection = false;
+    GeoSet sets[2];
+    int cur = 0;                            // set of the most recent select / render
     // QuadTree::SetHeight results: (position.y, extents.y) per node id; m_HeightLoaded
     float2* d_node_heights = nullptr;
     bool height_loaded = false;
     float texel_size[2] = { 0.0f, 0.0f };   // m_TexelSize (QuadTree.cpp:29)
     int surfaces_per_side = 1;              // WORLD_SIZE / SURFACE_SIZE (TerrainPass.cpp:97)
+    // Geometry stream: select / vertex / setup / bins depend only on the view, so they run on their own
+    // stream and overlap whatever the context's stream is doing (the lighting pass of the previous frame,
+    // or - after vr_terrain_prepare - its tile pass); the tile pass on the context's stream waits for them.
+    hipStream_t geo_stream = nullptr;
+    hipEvent_t ev_main_dep = nullptr, ev_raster_begin = nullptr;   // ev_raster_begin: the context's stream reached the last tile pass
+    bool main_dep_pending = false, raster_begin_recorded = false;
 };
 
 // ---- cross-TU entry points ----------------------------------------------------------
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
                           DevTex* out, uint8_t** out_mem);
-int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height);
+int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream);
 int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part);
 
 // ---- device helpers shared by kernels ---------------------------------------------------

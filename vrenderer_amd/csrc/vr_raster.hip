@@ -840,36 +840,20 @@ static uint32_t host_srgb_encode(const vr_context* c, float x)
     return (uint32_t)lo;
 }
 
-extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev, vr_gbuffer* gb,
-                                         const vr_render_params* rp, const vr_partition* part)
+static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_params* rp, int w, int h, const vr_partition* part,
+                            RasterArgs& a)
 {
-    (void)view_prev;   // MOTION_VECTORS = 0 (TerrainPass.cpp:361,368)
-    VR_REQUIRE(t && view && gb && rp, "NULL argument");
-    VR_REQUIRE(!rp->wireframe, "wireframe fill mode is not implemented");
-    VR_REQUIRE(!view->reverse_depth, "reverse depth is not supported (the reference disables it, Renderer.cpp:221)");
-    VR_REQUIRE(view->viewport_w > 0 && view->viewport_h > 0 && view->viewport_w <= 16384 && view->viewport_h <= 16384, "bad viewport");
-    VR_REQUIRE(gb->ctx == t->ctx, "G-buffer and terrain belong to different contexts");
-    vr_context* ctx = t->ctx;
-    VR_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    int rc;
-    if (!rp->lock_view || !t->have_selection) {                       // TerrainPass.cpp:173-190
-        if ((rc = vr_select_launch(t, view, rp->max_height))) return rc;
-    }
     const int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
     VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
-    if ((rc = vr_ensure_partition(ctx, gb->w, gb->h, part))) return rc;
-
-    RasterArgs a;
     memset(&a, 0, sizeof(a));
-    a.w = gb->w; a.h = gb->h;
+    a.w = w; a.h = h;
     a.vx0 = view->viewport_x; a.vy0 = view->viewport_y;
     a.vx1 = view->viewport_x + view->viewport_w - 1; a.vy1 = view->viewport_y + view->viewport_h - 1;
     if (a.vx0 < 0) a.vx0 = 0;
     if (a.vy0 < 0) a.vy0 = 0;
-    if (a.vx1 > gb->w - 1) a.vx1 = gb->w - 1;
-    if (a.vy1 > gb->h - 1) a.vy1 = gb->h - 1;
-    a.rtx = (gb->w + kRasterTile - 1) / kRasterTile; a.rty = (gb->h + kRasterTile - 1) / kRasterTile;
+    if (a.vx1 > w - 1) a.vx1 = w - 1;
+    if (a.vy1 > h - 1) a.vy1 = h - 1;
+    a.rtx = (w + kRasterTile - 1) / kRasterTile; a.rty = (h + kRasterTile - 1) / kRasterTile;
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared;
     a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
@@ -877,49 +861,137 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     a.bin_capacity = (uint32_t)t->bin_capacity;
     a.extra_vert_base = (uint32_t)t->p.max_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
     a.vp_x = (float)view->viewport_x; a.vp_y = (float)view->viewport_y; a.vp_w = (float)view->viewport_w; a.vp_h = (float)view->viewport_h;
+    return VR_OK;
+}
 
-    const int n_tiles = a.rtx * a.rty;
-    if (n_tiles > t->scratch_tiles) {
-        VR_HIP(hipStreamSynchronize(s));
-        (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_offset); (void)hipFree(t->d_tile_cursor);
-        t->d_tile_count = t->d_tile_offset = t->d_tile_cursor = nullptr; t->scratch_tiles = 0;
-        VR_HIP(hipMalloc(&t->d_tile_count, sizeof(uint32_t) * n_tiles));
-        VR_HIP(hipMalloc(&t->d_tile_offset, sizeof(uint32_t) * n_tiles));
-        VR_HIP(hipMalloc(&t->d_tile_cursor, sizeof(uint32_t) * n_tiles));
-        VR_HIP(hipMemsetAsync(t->d_tile_count, 0, sizeof(uint32_t) * n_tiles, s));   // k_scan re-zeroes it every frame
-        VR_HIP(hipMemsetAsync(t->d_tile_cursor, 0, sizeof(uint32_t) * n_tiles, s));
-        VR_HIP(hipMemsetAsync(t->d_tile_offset, 0, sizeof(uint32_t) * n_tiles, s));
-        t->scratch_tiles = n_tiles;
+// select -> vertex -> setup -> clip -> scan -> fill into `g`, on the geometry stream
+static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_from, const vr_view* view, const vr_render_params* rp,
+                           const RasterArgs& a)
+{
+    vr_context* ctx = t->ctx;
+    hipStream_t s = ctx->stream, gs = t->geo_stream;
+    if (!ctx->async_geometry) {          // single-stream mode: order the geometry behind everything queued so far
+        VR_HIP(hipEventRecord(t->ev_main_dep, s));
+        t->main_dep_pending = true;
     }
-
+    // after the tile pass that last read this set, and after anything the context's stream did to the terrain
+    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.ev_raster_done, 0));
+    if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); t->main_dep_pending = false; }
+    int rc;
+    if (selection_from == nullptr) {                                   // TerrainPass.cpp:173-190
+        if ((rc = vr_select_launch(t, g, view, rp->max_height, gs))) return rc;
+    } else if (selection_from != &g) {
+        // lockView: keep the selection of the last unlocked frame (TerrainPass.cpp:191-197); it lives in the other set
+        VR_HIP(hipMemcpyAsync(g.d_node_ids, selection_from->d_node_ids, (size_t)t->p.max_instances * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
+        VR_HIP(hipMemcpyAsync(g.d_instances, selection_from->d_instances, (size_t)t->p.max_instances * sizeof(vr_instance), hipMemcpyDeviceToDevice, gs));
+        VR_HIP(hipMemcpyAsync(g.d_counters, selection_from->d_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
+        g.have_selection = true;
+    }
+    const int n_tiles = a.rtx * a.rty;
+    if (n_tiles > g.scratch_tiles) {
+        VR_HIP(hipStreamSynchronize(gs));
+        VR_HIP(hipStreamSynchronize(s));
+        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor);
+        g.d_tile_count = g.d_tile_offset = g.d_tile_cursor = nullptr; g.scratch_tiles = 0;
+        VR_HIP(hipMalloc(&g.d_tile_count, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMalloc(&g.d_tile_offset, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMalloc(&g.d_tile_cursor, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMemsetAsync(g.d_tile_count, 0, sizeof(uint32_t) * n_tiles, gs));   // k_scan re-zeroes it every frame
+        VR_HIP(hipMemsetAsync(g.d_tile_cursor, 0, sizeof(uint32_t) * n_tiles, gs));
+        VR_HIP(hipMemsetAsync(g.d_tile_offset, 0, sizeof(uint32_t) * n_tiles, gs));
+        g.scratch_tiles = n_tiles;
+    }
     VertexArgs va;
     for (int i = 0; i < 16; i++) { va.w2v[i] = view->world_to_view[i]; va.v2c[i] = view->view_to_clip[i]; }
     va.cam_x = view->camera_pos[0]; va.cam_z = view->camera_pos[2];
     for (int i = 0; i < VR_MAX_LODS; i++) va.lod_ranges[i] = t->lod_ranges[i];
     va.morph_start = t->p.morph_start; va.world_size = t->p.world_size; va.max_height = rp->max_height;
     va.vp_x = a.vp_x; va.vp_y = a.vp_y; va.vp_w = a.vp_w; va.vp_h = a.vp_h;
+    { VrKernelScope ks(ctx, VR_K_VERTEX, gs);
+    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, gs, va, t->height, g.d_instances, g.d_counters, g.d_verts); }
+    { VrKernelScope ks(ctx, VR_K_SETUP, gs);
+    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count); }
+    { VrKernelScope ks(ctx, VR_K_CLIP, gs);
+    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count); }
+    { VrKernelScope ks(ctx, VR_K_SCAN, gs);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity); }
+    { VrKernelScope ks(ctx, VR_K_FILL, gs);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
+    VR_HIP(hipEventRecord(g.ev_geo_done, gs));
+    VR_HIP(hipGetLastError());
+    return VR_OK;
+}
 
-    HardTriRec* hard_tris = t->d_hard_tris;
-    { VrKernelScope ks(ctx, VR_K_VERTEX);
-    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, s, va, t->height, t->d_instances, t->d_counters, t->d_verts); }
-    { VrKernelScope ks(ctx, VR_K_SETUP);
-    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, s, a, t->d_verts, t->d_counters, t->d_rect, t->d_hard_list, t->d_tile_count); }
-    { VrKernelScope ks(ctx, VR_K_CLIP);
-    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, s, a, t->d_verts, t->d_counters, t->d_hard_list, hard_tris, t->d_hard_first, t->d_tile_count); }
-    { VrKernelScope ks(ctx, VR_K_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, n_tiles, t->d_tile_count, t->d_tile_offset, t->d_tile_cursor, t->d_counters, a.bin_capacity); }
-    { VrKernelScope ks(ctx, VR_K_FILL);
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, a, t->d_counters, t->d_rect, hard_tris, t->d_tile_cursor, t->d_bin_entries); }
+static int check_render_inputs(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp)
+{
+    VR_REQUIRE(t && view && gb && rp, "NULL argument");
+    VR_REQUIRE(!rp->wireframe, "wireframe fill mode is not implemented");
+    VR_REQUIRE(!view->reverse_depth, "reverse depth is not supported (the reference disables it, Renderer.cpp:221)");
+    VR_REQUIRE(view->viewport_w > 0 && view->viewport_h > 0 && view->viewport_w <= 16384 && view->viewport_h <= 16384, "bad viewport");
+    VR_REQUIRE(gb->ctx == t->ctx, "G-buffer and terrain belong to different contexts");
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp,
+                                          const vr_partition* part)
+{
+    int rc = check_render_inputs(t, view, gb, rp);
+    if (rc) return rc;
+    VR_REQUIRE(!rp->lock_view, "vr_terrain_prepare builds a new selection; it cannot be combined with lock_view");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    RasterArgs a;
+    if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
+    GeoSet& g = t->sets[t->cur ^ 1];
+    g.prepared = false;
+    // Start when the context's stream starts the tile pass queued last: the host runs frames ahead of the
+    // device, and without this the geometry would become runnable one pass earlier and share the device
+    // with the previous frame's lighting pass (bandwidth-bound) instead of with a tile pass (which leaves
+    // half of every CU's wave slots free).
+    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_raster_begin, 0));
+    if ((rc = launch_geometry(t, g, nullptr, view, rp, a))) return rc;
+    g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev, vr_gbuffer* gb,
+                                         const vr_render_params* rp, const vr_partition* part)
+{
+    (void)view_prev;   // MOTION_VECTORS = 0 (TerrainPass.cpp:361,368)
+    int rc = check_render_inputs(t, view, gb, rp);
+    if (rc) return rc;
+    vr_context* ctx = t->ctx;
+    VR_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    RasterArgs a;
+    if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
+    if ((rc = vr_ensure_partition(ctx, gb->w, gb->h, part))) return rc;
+
+    GeoSet& g = t->sets[t->cur ^ 1];
+    const GeoSet& last = t->sets[t->cur];
+    const bool use_prepared = g.prepared && !rp->lock_view && memcmp(&g.prep_view, view, sizeof(vr_view)) == 0
+                           && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only
+                           && g.prep_w == gb->w && g.prep_h == gb->h && g.prep_rank == a.rank && g.prep_world == a.world;
+    g.prepared = false;
+    if (!use_prepared) {
+        const GeoSet* sel = (rp->lock_view && last.have_selection) ? &last : nullptr;
+        if ((rc = launch_geometry(t, g, sel, view, rp, a))) return rc;
+    }
+    t->cur ^= 1;
+    VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));                    // the tile pass consumes verts + bins
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
-    const bool whole = world <= 1;
-    const int grid = whole ? n_tiles : ctx->num_raster_tiles;
+    const bool whole = a.world <= 1;
+    const int grid = whole ? a.rtx * a.rty : ctx->num_raster_tiles;
+    VR_HIP(hipEventRecord(t->ev_raster_begin, s));
+    t->raster_begin_recorded = true;
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER);
-        hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, t->d_verts, hard_tris, t->d_hard_first,
-                           t->d_tile_cursor, t->d_tile_offset, t->d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
+        hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
+                           g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
+    VR_HIP(hipEventRecord(g.ev_raster_done, s));
+    g.raster_recorded = true;
     VR_HIP(hipGetLastError());
     return VR_OK;
 }

@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 constexpr int kSelThreads = 1024;
 constexpr int kFrontierCap = 4096;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     }
 }
 
-int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
+int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream)
 {
     SelectArgs a;
     for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.loc[i] = t->p.location[i]; }
@@ -201,11 +202,11 @@ int vr_select_launch(vr_terrain* t, const vr_view* view, float max_height)
     a.surfaces_per_side = t->surfaces_per_side; a.num_surfaces = t->surfaces_per_side * t->surfaces_per_side;
     a.surface_size = t->p.surface_size;
     a.nodes_per_tree = (uint32_t)((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
-    VrKernelScope ks(t->ctx, VR_K_SELECT);
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, t->ctx->stream, a, t->d_node_ids, t->d_instances, t->d_counters,
+    VrKernelScope ks(t->ctx, VR_K_SELECT, stream);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, stream, a, g.d_node_ids, g.d_instances, g.d_counters,
                        (const float2*)t->d_node_heights);
     VR_HIP(hipGetLastError());
-    t->have_selection = true;
+    g.have_selection = true;
     return VR_OK;
 }
 
@@ -325,6 +326,9 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
     }
     }
     VR_HIP(hipGetLastError());
+    // NodeSelect runs on the geometry stream: make it see these results
+    VR_HIP(hipEventRecord(t->ev_main_dep, t->ctx->stream));
+    t->main_dep_pending = true;
     t->height_loaded = true;
     return VR_OK;
 }
@@ -377,18 +381,32 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
     t->extra_vert_cap = 1u << 16; t->hard_cap = 1u << 15;
 #define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
         vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); vr_terrain_destroy(t); return VR_ERR_OUT_OF_MEMORY; } } while (0)
-    VR_ALLOC(t->d_node_ids, mi * sizeof(uint32_t));
-    VR_ALLOC(t->d_instances, mi * sizeof(vr_instance));
-    VR_ALLOC(t->d_counters, 64 * sizeof(uint32_t));
-    VR_ALLOC(t->d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
-    VR_ALLOC(t->d_rect, mi * kTrisPerInst * sizeof(uint64_t));
-    VR_ALLOC(t->d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
-    VR_ALLOC(t->d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
-    VR_ALLOC(t->d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
     t->bin_capacity = (size_t)16 << 20;
-    VR_ALLOC(t->d_bin_entries, t->bin_capacity * sizeof(uint32_t));
+    for (GeoSet& g : t->sets) {
+        VR_ALLOC(g.d_node_ids, mi * sizeof(uint32_t));
+        VR_ALLOC(g.d_instances, mi * sizeof(vr_instance));
+        VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
+        VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
+        VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
+        VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
+        VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
+        VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
+        VR_ALLOC(g.d_bin_entries, t->bin_capacity * sizeof(uint32_t));
+    }
 #undef VR_ALLOC
-    VR_HIP(hipMemsetAsync(t->d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+    for (GeoSet& g : t->sets) {
+        VR_HIP(hipMemsetAsync(g.d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
+        VR_HIP(hipEventCreateWithFlags(&g.ev_geo_done, hipEventDisableTiming));
+        VR_HIP(hipEventCreateWithFlags(&g.ev_raster_done, hipEventDisableTiming));
+    }
+    VR_HIP(hipStreamSynchronize(ctx->stream));
+    {   // lowest priority: geometry fills in around the lighting pass without taking its CUs away
+        int least = 0, greatest = 0;
+        VR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        VR_HIP(hipStreamCreateWithPriority(&t->geo_stream, hipStreamNonBlocking, getenv("VR_GEO_PRIO_HIGH") ? greatest : least));
+    }
+    VR_HIP(hipEventCreateWithFlags(&t->ev_main_dep, hipEventDisableTiming));
+    VR_HIP(hipEventCreateWithFlags(&t->ev_raster_begin, hipEventDisableTiming));
     *out = t;
     return VR_OK;
 }
@@ -398,10 +416,17 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_ids); (void)hipFree(t->d_instances);
-    (void)hipFree(t->d_counters); (void)hipFree(t->d_verts); (void)hipFree(t->d_rect); (void)hipFree(t->d_hard_list);
-    (void)hipFree(t->d_hard_tris); (void)hipFree(t->d_hard_first); (void)hipFree(t->d_tile_count); (void)hipFree(t->d_tile_offset);
-    (void)hipFree(t->d_tile_cursor); (void)hipFree(t->d_bin_entries); (void)hipFree(t->d_node_heights);
+    if (t->geo_stream) { (void)hipStreamSynchronize(t->geo_stream); (void)hipStreamDestroy(t->geo_stream); }
+    if (t->ev_main_dep) (void)hipEventDestroy(t->ev_main_dep);
+    if (t->ev_raster_begin) (void)hipEventDestroy(t->ev_raster_begin);
+    for (GeoSet& g : t->sets) {
+        if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
+        if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
+        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
+        (void)hipFree(g.d_rect); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
+        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_bin_entries);
+    }
+    (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights);
     delete t;
 }
 
@@ -436,7 +461,8 @@ extern "C" VR_API int vr_terrain_download_mip(vr_terrain* t, int which, int leve
 static int read_counters(vr_terrain* t, uint32_t* count)
 {
     uint32_t c[4] = { 0, 0, 0, 0 };
-    VR_HIP(hipMemcpyAsync(c, t->d_counters, sizeof(c), hipMemcpyDeviceToHost, t->ctx->stream));
+    VR_HIP(hipStreamSynchronize(t->geo_stream));          // selection and bins are produced on the geometry stream
+    VR_HIP(hipMemcpyAsync(c, t->sets[t->cur].d_counters, sizeof(c), hipMemcpyDeviceToHost, t->ctx->stream));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
     if (count) *count = c[0];
     if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
@@ -449,14 +475,21 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
 {
     VR_REQUIRE(t && view, "NULL argument");
     VR_HIP(hipSetDevice(t->ctx->device));
-    int rc = vr_select_launch(t, view, max_height);
+    // the selection buffers are consumed by geometry-stream kernels: order this launch behind them and
+    // behind whatever the context's stream did to the terrain (heights)
+    if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_main_dep, 0)); t->main_dep_pending = false; }
+    GeoSet& g = t->sets[t->cur ^ 1];                               // the set no tile pass in flight is reading
+    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, g.ev_raster_done, 0));
+    g.prepared = false;
+    int rc = vr_select_launch(t, g, view, max_height, t->geo_stream);
     if (rc) return rc;
+    t->cur ^= 1;
     if (!node_ids && !instances && !count) return VR_OK;       // stays asynchronous
     uint32_t n = 0;
     rc = read_counters(t, &n);
     if (count) *count = n;
-    if (node_ids && n) VR_HIP(hipMemcpy(node_ids, t->d_node_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (instances && n) VR_HIP(hipMemcpy(instances, t->d_instances, n * sizeof(vr_instance), hipMemcpyDeviceToHost));
+    if (node_ids && n) VR_HIP(hipMemcpy(node_ids, g.d_node_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (instances && n) VR_HIP(hipMemcpy(instances, g.d_instances, n * sizeof(vr_instance), hipMemcpyDeviceToHost));
     return rc;
 }
 
@@ -464,7 +497,7 @@ extern "C" VR_API int vr_terrain_num_chunks(vr_terrain* t, uint32_t* count)
 {
     VR_REQUIRE(t && count, "NULL argument");
     VR_HIP(hipSetDevice(t->ctx->device));
-    if (!t->have_selection) { *count = 0; return VR_OK; }
+    if (!t->sets[t->cur].have_selection) { *count = 0; return VR_OK; }
     return read_counters(t, count);
 }
 
@@ -472,13 +505,15 @@ extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
 {
     VR_REQUIRE(t && out, "NULL argument");
     VR_HIP(hipSetDevice(t->ctx->device));
+    VR_HIP(hipStreamSynchronize(t->geo_stream));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
-    VR_HIP(hipMemcpy(out, t->d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const GeoSet& g = t->sets[t->cur];
+    VR_HIP(hipMemcpy(out, g.d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     out[6] = 0; out[7] = 0;
-    if (t->scratch_tiles > 0 && t->d_tile_cursor) {
-        std::vector<uint32_t> c((size_t)t->scratch_tiles), o((size_t)t->scratch_tiles);
-        VR_HIP(hipMemcpy(c.data(), t->d_tile_cursor, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        VR_HIP(hipMemcpy(o.data(), t->d_tile_offset, o.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (g.scratch_tiles > 0 && g.d_tile_cursor) {
+        std::vector<uint32_t> c((size_t)g.scratch_tiles), o((size_t)g.scratch_tiles);
+        VR_HIP(hipMemcpy(c.data(), g.d_tile_cursor, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        VR_HIP(hipMemcpy(o.data(), g.d_tile_offset, o.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < c.size(); i++) { const uint32_t v = c[i] - o[i]; if (v > out[6]) out[6] = v; if (v) out[7]++; }
     }
     return VR_OK;

@@ -36,6 +36,10 @@ class Context:
     def synchronize(self):
         check(self.lib.vr_context_synchronize(self.handle), "vr_context_synchronize")
 
+    def set_async_geometry(self, enable):
+        """Geometry stages of TerrainPass.Render on a second stream (overlaps the previous frame's lighting)."""
+        check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_ASYNC_GEOMETRY, int(enable)), "vr_context_set_option")
+
     def timing_enable(self, enable=True):
         check(self.lib.vr_timing_enable(self.handle, int(enable)), "vr_timing_enable")
 
@@ -260,6 +264,11 @@ class TerrainPass:
         check(self.ctx.lib.vr_debug_render_stats(self.handle, out), "vr_debug_render_stats")
         keys = ("nodes", "flags", "clip_subtris", "clip_verts", "clipped_tris", "bin_entries", "max_bin", "nonempty_bins")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def Prepare(self, view, render_targets, render_params, partition=None):
+        """Build the next frame's geometry ahead of time (overlaps the current frame's tile pass)."""
+        check(self.ctx.lib.vr_terrain_prepare(self.handle, C.byref(view), render_targets.handle, C.byref(render_params),
+                                              C.byref(partition) if partition is not None else None), "vr_terrain_prepare")
 
     def num_chunks(self):
         """EditorParams::m_NumChunks (TerrainPass.cpp:198); synchronises."""
