@@ -558,3 +558,41 @@ def test_full_size_8k_properties(scene2048, gpu_ctx):
     assert np.array_equal(out.download(), ref)
     for o in (big, out, full, rt):
         o.close()
+
+
+def test_prepared_geometry_is_equivalent(scene256, oracle, gpu_ctx):
+    """vr_terrain_prepare only moves work in time: a prepared frame, a frame whose prepared geometry does
+    not match (discarded) and a frame rendered on one stream all equal the oracle."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 512, 288
+    va = vr.make_view(*scaled_camera(CAMERAS[0], 256), w, h)
+    vb = vr.make_view(*scaled_camera(CAMERAS[5], 256), w, h)
+    rp = vr.default_render_params(400.0)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    want = {}
+    for name, v in (("a", va), ("b", vb)):
+        gb = oracle.GBufferHost(w, h)
+        ot.render(v, gb, rp)
+        want[name] = gb
+
+    def check(v, key, what):
+        planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+        _assert_gbuffer_equal(want[key], planes, what)
+
+    rt.Clear(); tp.Prepare(va, rt, rp); tp.Render(va, va, rt, rp); check(va, "a", "prepared")
+    rt.Clear(); tp.Prepare(va, rt, rp); tp.Render(vb, vb, rt, rp); check(vb, "b", "stale prepare discarded")
+    rt.Clear(); tp.Prepare(vb, rt, rp); tp.Prepare(va, rt, rp); tp.Render(va, va, rt, rp); check(va, "a", "re-prepared")
+    # a chain of frames, each preparing the next one (the bench's pattern)
+    seq = [va, vb, va, vb, vb, va]
+    for i, v in enumerate(seq):
+        rt.Clear()
+        tp.Render(v, v, rt, rp)
+        if i + 1 < len(seq):
+            tp.Prepare(seq[i + 1], rt, rp)
+        check(v, "a" if v is va else "b", f"chain {i}")
+    gpu_ctx.set_async_geometry(False)
+    try:
+        rt.Clear(); tp.Render(vb, vb, rt, rp); check(vb, "b", "single stream")
+    finally:
+        gpu_ctx.set_async_geometry(True)
+    rt.close()
