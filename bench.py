@@ -144,10 +144,11 @@ def main():
         # i+1 is rendered (the collective reads packed[b] / writes gathered[b], the renderer does not).
         nbuf = 1 if args.no_overlap else 2
         half_elems = info["packed_bytes"] // 2
-        packed = [torch.empty(half_elems, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
         gathered = [torch.empty(world * half_elems, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
-        # packed tile-major buffer: max_owned tiles of 128x128 RGBA16F, equal on every rank
-        hdr_bufs = [vr.HdrImage(ctx, vr.VR_OWNER_TILE, info["max_owned"] * vr.VR_OWNER_TILE, external_ptr=t.data_ptr()) for t in packed]
+        # packed tile-major buffer: max_owned tiles of 128x128 RGB16F (6 B/px), equal on every rank
+        rows = (info["packed_bytes"] + vr.VR_OWNER_TILE * 8 - 1) // (vr.VR_OWNER_TILE * 8)     # image wrapper sized in 8-B pixels
+        packed = [torch.empty(rows * vr.VR_OWNER_TILE * 4, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
+        hdr_bufs = [vr.HdrImage(ctx, vr.VR_OWNER_TILE, rows, external_ptr=t.data_ptr()) for t in packed]
         main_stream = torch.cuda.current_stream()
         if nbuf > 1:
             comm_stream = torch.cuda.Stream()
@@ -189,7 +190,7 @@ def main():
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
-            dist.all_gather_into_tensor(gathered[b], packed[b])      # RCCL over xGMI, equal send counts
+            dist.all_gather_into_tensor(gathered[b], packed[b][:half_elems])      # RCCL over xGMI, equal send counts
             frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
             comm_done[b].record(comm_stream)
 

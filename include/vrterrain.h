@@ -265,8 +265,9 @@ VR_API size_t vr_partition_packed_bytes(int32_t width, int32_t height, int32_t w
 /* Builds the partition tables of a context up front (they are otherwise built on first use by
  * vr_terrain_render / vr_deferred_light); needed when vr_frame_detile runs on its own context/stream. */
 VR_API int    vr_partition_prepare(vr_context* ctx, int32_t width, int32_t height, const vr_partition* part);
-/* After the all-gather: gathered = world_size consecutive packed buffers (device
- * pointer); rebuilds the row-major RGBA16F frame. */
+/* After the all-gather: gathered = world_size consecutive packed buffers (device pointer; packed
+ * tiles are RGB16F, 6 B/pixel - HdrColor's alpha is always 0 on this path and is not exchanged);
+ * rebuilds the row-major RGBA16F frame. */
 VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int32_t world_size,
                               vr_image* frame_out);
 

@@ -72,7 +72,7 @@ def test_partition_tables_agree_with_python_mirror(product_lib, w, h, world):
         assert (info["tiles_x"], info["tiles_y"]) == (tx, ty)
         assert info["owned"] == len(pt.owned_tiles(w, h, r, world))
         assert info["max_owned"] == pt.max_owned(w, h, world)
-        assert info["packed_bytes"] == pt.max_owned(w, h, world) * 128 * 128 * 8
+        assert info["packed_bytes"] == pt.max_owned(w, h, world) * 128 * 128 * 6
         counts.append(info["owned"])
     assert sum(counts) == tx * ty
     if (w, h, world) == (7680, 4320, 8):
@@ -115,6 +115,7 @@ def test_pack_detile_roundtrip_numpy():
     rng = np.random.default_rng(3)
     for (w, h, world) in ((300, 260, 3), (512, 256, 2), (130, 70, 8)):
         frame = rng.integers(0, 65535, (h, w, 4), dtype=np.uint16)
+        frame[..., 3] = 0                                  # HdrColor's alpha is 0 on this path and is not exchanged
         gathered = np.concatenate([pt.pack(frame, r, world) for r in range(world)], 0)
         assert np.array_equal(pt.detile(gathered, w, h, world), frame)
 

@@ -422,7 +422,7 @@ extern "C" VR_API size_t vr_partition_packed_bytes(int32_t w, int32_t h, int32_t
     vr_partition p = { 0, world };
     int32_t mo = 0;
     vr_partition_num_tiles(w, h, &p, nullptr, nullptr, nullptr, &mo);
-    return (size_t)mo * VR_OWNER_TILE * VR_OWNER_TILE * 8;
+    return (size_t)mo * VR_OWNER_TILE * VR_OWNER_TILE * 6;      // RGB16F: the always-zero alpha is not exchanged
 }
 
 extern "C" VR_API int vr_partition_prepare(vr_context* ctx, int32_t w, int32_t h, const vr_partition* part)

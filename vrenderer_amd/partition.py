@@ -5,7 +5,8 @@ runs those on the device; this module is what host code — bench.py, tests — 
 reason about the same layout):
 
   * owner tiles are 128x128 pixels, owner(tx, ty) = (tx + ty) mod world_size;
-  * a rank's packed buffer is [local tile][128 rows][128 px] RGBA16F, local tiles in
+  * a rank's packed buffer is [local tile][128 rows][128 px] RGB16F (alpha is always 0 and is
+    not exchanged), local tiles in
     row-major order of the rank's owned tiles, padded to `max_owned` tiles so that every
     rank's all-gather send count is equal;
   * after the all-gather, tile t of the frame lives at slot owner*max_owned + local.
@@ -43,29 +44,29 @@ def tile_slots(width, height, world):
 
 
 def packed_shape(width, height, world):
-    return (max_owned(width, height, world), TILE, TILE, 4)
+    return (max_owned(width, height, world), TILE, TILE, 3)
 
 
 def pack(frame, rank, world):
-    """frame: (H, W, 4) uint16 -> this rank's packed tiles (max_owned, 128, 128, 4), zero padded."""
+    """frame: (H, W, 4) uint16 -> this rank's packed tiles (max_owned, 128, 128, 3), zero padded."""
     h, w = frame.shape[:2]
     tx, _ = owner_grid(w, h)
     out = np.zeros(packed_shape(w, h, world), frame.dtype)
     for i, t in enumerate(owned_tiles(w, h, rank, world)):
         y0, x0 = (t // tx) * TILE, (t % tx) * TILE
-        blk = frame[y0:y0 + TILE, x0:x0 + TILE]
+        blk = frame[y0:y0 + TILE, x0:x0 + TILE, :3]
         out[i, :blk.shape[0], :blk.shape[1]] = blk
     return out
 
 
 def detile(gathered, width, height, world):
-    """gathered: (world * max_owned, 128, 128, 4) -> (H, W, 4) frame."""
+    """gathered: (world * max_owned, 128, 128, 3) -> (H, W, 4) frame (alpha 0)."""
     tx, ty = owner_grid(width, height)
     slot = tile_slots(width, height, world)
-    g = gathered.reshape(-1, TILE, TILE, 4)
+    g = gathered.reshape(-1, TILE, TILE, 3)
     out = np.zeros((height, width, 4), gathered.dtype)
     for t in range(tx * ty):
         y0, x0 = (t // tx) * TILE, (t % tx) * TILE
         hh, ww = min(TILE, height - y0), min(TILE, width - x0)
-        out[y0:y0 + hh, x0:x0 + ww] = g[slot[t], :hh, :ww]
+        out[y0:y0 + hh, x0:x0 + ww, :3] = g[slot[t], :hh, :ww]
     return out
