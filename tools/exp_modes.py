@@ -7,6 +7,8 @@ from bench import flythrough_camera
 
 W, H, size = int(os.environ.get("W", 7680)), int(os.environ.get("H", 4320)), 2048
 ctx = vr.Context(0)
+ctx.set_async_geometry(False)   # clean per-kernel numbers
+ctx.set_async_geometry(False)   # clean per-kernel numbers
 hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
 tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
 rt = vr.RenderTargets(ctx).Init(W, H)
