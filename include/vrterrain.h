@@ -98,7 +98,9 @@ typedef struct vr_render_params {
     int32_t reserved[3];
 } vr_render_params;
 
-/* Donut LightConstants subset consumed by the deferred pass. */
+/* Donut LightConstants subset consumed by the deferred pass (ShadeSurface): directional lights
+ * (direction, irradiance, angular size), point and spot lights (position, 1/range, optional source
+ * radius; spot: cone axis = direction, inner/outer half angles in radians). */
 enum { VR_LIGHT_DIRECTIONAL = 1, VR_LIGHT_SPOT = 2, VR_LIGHT_POINT = 3 };
 typedef struct vr_light {
     float   direction[3];  int32_t type;

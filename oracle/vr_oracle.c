@@ -941,10 +941,11 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
     for (int i = 0; i < nl; i++) {
         const vr_light* L_ = &lights[i];
         float Lin[3], irr;
+        float cosH = lc[i].cosH, sinH = lc[i].sinH, tanH = lc[i].tanH;
         if (L_->type == VR_LIGHT_DIRECTIONAL) {
             Lin[0] = L_->direction[0]; Lin[1] = L_->direction[1]; Lin[2] = L_->direction[2];
             irr = L_->intensity;
-        } else {   /* point */
+        } else {   /* spot or point (ShadeSurface) */
             float lts[3] = { wp[0] - L_->position[0], wp[1] - L_->position[1], wp[2] - L_->position[2] };
             float dist = sqrtf(dot3(lts, lts));
             float rd = 1.0f / dist;
@@ -957,7 +958,25 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
                 att = s * s;
                 if (att == 0.0f) continue;
             }
-            irr = (L_->intensity * (rd * rd)) * att;
+            float spotlight = 1.0f;
+            if (L_->type == VR_LIGHT_SPOT) {
+                float LdotD = fminx(fmaxx(dot3(Lin, L_->direction), -1.0f), 1.0f);
+                float directionAngle = acosf(LdotD);
+                float ts = saturatef((directionAngle - L_->inner_angle) / (L_->outer_angle - L_->inner_angle));
+                spotlight = 1.0f - ts * ts * (3.0f - 2.0f * ts);        /* 1 - smoothstep(inner, outer, angle) */
+                if (spotlight == 0.0f) continue;
+            }
+            if (L_->radius > 0.0f) {
+                /* spherical source: half angle atan(min(radius / distance, 1)); its sin/cos/tan in closed form */
+                float x = fminx(L_->radius * rd, 1.0f);
+                float halfAng = atanf(x);
+                float radianceTimesPi = L_->intensity / (L_->radius * L_->radius);
+                irr = radianceTimesPi * (halfAng * halfAng);
+                tanH = x; cosH = 1.0f / sqrtf(1.0f + x * x); sinH = x * cosH;
+            } else {
+                irr = L_->intensity * (rd * rd);
+            }
+            irr = irr * (spotlight * att);
         }
         float L[3] = { -Lin[0], -Lin[1], -Lin[2] };
         /* diffuse: Lambert */
@@ -966,11 +985,11 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
         /* specular: GGX with area-light correction */
         float cosT = fminx(fmaxx(dot3(R, L), -1.0f), 1.0f);
         float CL[3];
-        if (cosT >= lc[i].cosH) { CL[0] = R[0]; CL[1] = R[1]; CL[2] = R[2]; }
+        if (cosT >= cosH) { CL[0] = R[0]; CL[1] = R[1]; CL[2] = R[2]; }
         else {
             float sinT = sqrtf(fmaxx(1.0f - cosT * cosT, 1e-12f));
-            float k2 = lc[i].sinH / sinT;
-            float k1 = lc[i].cosH - cosT * k2;
+            float k2 = sinH / sinT;
+            float k1 = cosH - cosT * k2;
             for (int c = 0; c < 3; c++) CL[c] = L[c] * k1 + R[c] * k2;
         }
         float Hv[3] = { CL[0] + V[0], CL[1] + V[1], CL[2] + V[2] };
@@ -978,7 +997,7 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
         float hs = hl2 > 0.0f ? 1.0f / sqrtf(hl2) : 0.0f;
         Hv[0] *= hs; Hv[1] *= hs; Hv[2] *= hs;
         float NdotH = saturatef(dot3(N, Hv)), NdotL = saturatef(dot3(N, CL)), VdotH = saturatef(dot3(V, Hv));
-        float corrAlpha = saturatef(alpha + 0.5f * lc[i].tanH);
+        float corrAlpha = saturatef(alpha + 0.5f * tanH);
         float sn = alpha / corrAlpha; sn = sn * sn;
         float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
         float D = (a2 / (ORC_PI * (dd * dd))) * sn;

@@ -596,3 +596,31 @@ def test_prepared_geometry_is_equivalent(scene256, oracle, gpu_ctx):
     finally:
         gpu_ctx.set_async_geometry(True)
     rt.close()
+
+
+def test_deferred_spot_and_spherical_lights(scene256, oracle, gpu_ctx):
+    """All three Donut light types through the streaming pass (ShadeSurface: cone falloff by
+    1 - smoothstep(inner, outer, angle), spherical sources with a per-pixel half angle)."""
+    w, h = 320, 180
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v, gb_o, planes, _, _ = _render_both(scene256, oracle, gpu_ctx, eye, tgt, w, h)
+    lights = [vr.reference_sun(), vr.point_light((10.0, 40.0, -5.0), 3000.0, 120.0, (1.0, 0.5, 0.25)),
+              vr.spot_light((-20.0, 60.0, 10.0), (0.3, -1.0, -0.2), 6000.0, 200.0, 12.0, 25.0, (0.2, 1.0, 0.4)),
+              vr.point_light((30.0, 35.0, -30.0), 2000.0, 150.0, (0.9, 0.9, 1.0), radius=6.0),
+              vr.spot_light((0.0, 80.0, -40.0), (0.0, -1.0, 0.3), 9000.0, 0.0, 5.0, 40.0, (1.0, 0.2, 0.2), radius=3.0)]
+    ref32 = oracle.deferred(v, gb_o, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    base = oracle.deferred(v, gb_o, lights[:2], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    assert np.abs(ref32 - base).max() > 1e-3
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    for k, arr in (("depth", gb_o.depth), ("diffuse", gb_o.diffuse), ("specular", gb_o.specular),
+                   ("normals", gb_o.normals), ("emissive", gb_o.emissive)):
+        rt.upload(k, arr)
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    for c in range(3):
+        assert np.sqrt(np.mean((got[..., c] - ref32[..., c]) ** 2)) <= 1e-4
+    with pytest.raises(vr.VrError):           # the tiled pass takes directional + punctual point lights only
+        vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    hdr.close()
+    rt.close()

@@ -178,7 +178,7 @@ def _shade_numpy(view, gb, lights, amb_top, amb_bot, oracle):
     dterm = np.zeros_like(alb)
     sterm = np.zeros_like(alb)
     for l in lights:
-        half = 0.5 * l.angular_size_or_inv_range if l.type == vr.VR_LIGHT_DIRECTIONAL else 0.0
+        half = (0.5 * l.angular_size_or_inv_range if l.type == vr.VR_LIGHT_DIRECTIONAL else 0.0) * np.ones(wp.shape[:2])
         if l.type == vr.VR_LIGHT_DIRECTIONAL:
             L = -np.array(l.direction[:], np.float64) * np.ones_like(wp)
             irr = l.intensity * np.ones(wp.shape[:2])
@@ -189,7 +189,17 @@ def _shade_numpy(view, gb, lights, amb_top, amb_bot, oracle):
             att = np.ones_like(dist)
             if l.angular_size_or_inv_range > 0:
                 att = np.clip(1 - (dist * l.angular_size_or_inv_range) ** 4, 0, 1) ** 2
-            irr = l.intensity / dist ** 2 * att
+            spot = np.ones_like(dist)
+            if l.type == vr.VR_LIGHT_SPOT:
+                ang = np.arccos(np.clip((-L * np.array(l.direction[:], np.float64)).sum(-1), -1, 1))
+                ts = np.clip((ang - l.inner_angle) / (l.outer_angle - l.inner_angle), 0, 1)
+                spot = 1 - ts * ts * (3 - 2 * ts)
+            if l.radius > 0:
+                half = np.arctan(np.minimum(l.radius / dist, 1.0))
+                irr = l.intensity / l.radius ** 2 * half ** 2
+            else:
+                irr = l.intensity / dist ** 2
+            irr = irr * spot * att
         kd = np.maximum((N * L).sum(-1), 0) / np.pi * irr
         cosT = np.clip((R * L).sum(-1), -1, 1)
         ang = np.arccos(cosT)
@@ -205,7 +215,7 @@ def _shade_numpy(view, gb, lights, amb_top, amb_bot, oracle):
         ndh = np.clip((N * H).sum(-1), 0, 1)
         ndl = np.clip((N * CL).sum(-1), 0, 1)
         vdh = np.clip((V * H).sum(-1), 0, 1)
-        ca = np.clip(alpha + 0.5 * np.tan(half), 0, 1)
+        ca = np.clip(alpha + 0.5 * np.tan(half), 0, 1)   # half may vary per pixel (spherical sources)
         D = alpha ** 2 / (np.pi * (ndh ** 2 * (alpha ** 2 - 1) + 1) ** 2) * (alpha / ca) ** 2
         G = 1 / ((ndl * (1 - kk) + kk) * (ndv * (1 - kk) + kk))
         F = f0 + (1 - f0) * ((1 - vdh) ** 5)[..., None]
@@ -226,8 +236,13 @@ def test_deferred_matches_independent_float64_model(oracle):
     for name in ("depth", "diffuse", "specular", "normals", "emissive"):
         getattr(gb, name)[...] = g[name]
     v = vr.View.from_buffer_copy(g["view"].tobytes())
-    lights = [vr.reference_sun(), vr.point_light((10.0, 40.0, -5.0), 3000.0, 120.0, (1.0, 0.5, 0.25))]
+    lights = [vr.reference_sun(), vr.point_light((10.0, 40.0, -5.0), 3000.0, 120.0, (1.0, 0.5, 0.25)),
+              vr.spot_light((-20.0, 60.0, 10.0), (0.3, -1.0, -0.2), 6000.0, 200.0, 12.0, 25.0, (0.2, 1.0, 0.4)),
+              vr.point_light((30.0, 35.0, -30.0), 2000.0, 150.0, (0.9, 0.9, 1.0), radius=6.0),
+              vr.spot_light((0.0, 80.0, -40.0), (0.0, -1.0, 0.3), 9000.0, 0.0, 5.0, 40.0, (1.0, 0.2, 0.2), radius=3.0)]
     got = oracle.deferred(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)[..., :3]
+    only_sun = oracle.deferred(v, gb, lights[:1], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)[..., :3]
+    assert np.abs(got - only_sun).max() > 1e-3, "the local lights must reach the terrain"
     want = _shade_numpy(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, oracle)
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 

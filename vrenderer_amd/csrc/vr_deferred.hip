@@ -89,8 +89,12 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
 
 // One light's contribution (ShadeSurface + GGX_AnalyticalLights_times_NdotL).  type/vec/inv_range etc.
 // are the DevLight fields; passed separately so that they may come from SGPRs or from LDS.
+// Spot cone and spherical-source terms of ShadeSurface (only evaluated for such lights).
+struct LightExtra { float axis[3]; float radius, inner_angle, outer_angle; };
+
 __device__ __forceinline__ void add_light(const Surface& s, int type, const float vec[3], float inv_range, const float color[3],
-                                          float intensity, float cosH, float sinH, float tanH, float diffuseTerm[3], float specularTerm[3])
+                                          float intensity, float cosH, float sinH, float tanH, float diffuseTerm[3], float specularTerm[3],
+                                          const LightExtra* extra = nullptr)
 {
 #pragma clang fp contract(fast)
     float L[3], irr;                                                  // L = -incidentVector
@@ -109,7 +113,23 @@ __device__ __forceinline__ void add_light(const Surface& s, int type, const floa
             att = sa * sa;
             if (att == 0.0f) return;
         }
-        irr = (intensity * (rd * rd)) * att;
+        irr = intensity * (rd * rd);
+        if (extra != nullptr) {
+            if (type == VR_LIGHT_SPOT) {
+                const float LdotD = vr_min(vr_max(-dot3c(L[0], L[1], L[2], extra->axis[0], extra->axis[1], extra->axis[2]), -1.0f), 1.0f);
+                const float ts = vr_saturate((acosf(LdotD) - extra->inner_angle) * fast_rcp(extra->outer_angle - extra->inner_angle));
+                const float spotlight = 1.0f - ts * ts * (3.0f - 2.0f * ts);
+                if (spotlight == 0.0f) return;
+                att *= spotlight;
+            }
+            if (extra->radius > 0.0f) {
+                const float x = vr_min(extra->radius * rd, 1.0f);
+                const float halfAng = atanf(x);
+                irr = (intensity * fast_rcp(extra->radius * extra->radius)) * (halfAng * halfAng);
+                tanH = x; cosH = fast_rsq(1.0f + x * x); sinH = x * cosH;
+            }
+        }
+        irr *= att;
     }
     const float NdotLd = vr_max(dot3c(s.N[0], s.N[1], s.N[2], L[0], L[1], L[2]), 0.0f);
     const float kd = (NdotLd * VR_INV_PI) * irr;
@@ -157,6 +177,9 @@ __device__ __forceinline__ void finish_pixel(const DeferredArgs& a, const Surfac
     }
 }
 
+// EXTRA: the light list contains spot or spherical lights (compiled out of the common variant, which
+// keeps the streaming kernel at its leanest for directional / punctual lights).
+template <bool EXTRA>
 __device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
                                             uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
                                             float out[3])
@@ -166,7 +189,13 @@ __device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* 
     for (int i = 0; i < a.num_lights; i++) {
         const DevLight& Lc = a.lights[i];
         const float* vec = Lc.type == VR_LIGHT_DIRECTIONAL ? Lc.dir : Lc.pos;
-        add_light(s, Lc.type, vec, Lc.inv_range, Lc.color, Lc.intensity, Lc.cosH, Lc.sinH, Lc.tanH, diffuseTerm, specularTerm);
+        if (EXTRA && (Lc.type == VR_LIGHT_SPOT || Lc.radius > 0.0f)) {
+            LightExtra ex; ex.axis[0] = Lc.dir[0]; ex.axis[1] = Lc.dir[1]; ex.axis[2] = Lc.dir[2];
+            ex.radius = Lc.radius; ex.inner_angle = Lc.inner_angle; ex.outer_angle = Lc.outer_angle;
+            add_light(s, Lc.type, vec, Lc.inv_range, Lc.color, Lc.intensity, Lc.cosH, Lc.sinH, Lc.tanH, diffuseTerm, specularTerm, &ex);
+        } else {
+            add_light(s, Lc.type, vec, Lc.inv_range, Lc.color, Lc.intensity, Lc.cosH, Lc.sinH, Lc.tanH, diffuseTerm, specularTerm);
+        }
     }
     finish_pixel(a, s, diffuseTerm, specularTerm, out);
 }
@@ -192,7 +221,7 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
 // PACKED = false: whole frame, row-major output; one lane = 4 consecutive pixels.
 // PACKED = true : only owner tiles of this rank, output packed tile-major
 //                 [local tile][128 rows][128 px]; block = 8 rows x 128 px of a tile.
-template <bool PACKED>
+template <bool PACKED, bool EXTRA>
 __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                    const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* _
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float rgb[3];
-        shade_pixel(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb);
+        shade_pixel<EXTRA>(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb);
         o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
         o[2 * k + 1] = vr_float_to_half(rgb[2]);          // alpha = 0
     }
@@ -261,19 +290,23 @@ __global__ __launch_bounds__(256) void k_deferred_scalar(DeferredArgs a, const f
     const int py = (int)(p / (size_t)a.w), px = (int)(p - (size_t)py * a.w);
     const uint2 n = g_nrm[p], e = g_emi[p];
     float rgb[3];
-    shade_pixel(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb);
+    shade_pixel<true>(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb);
     out[p] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
 }
 
-static int fill_light(const vr_light& l, DevLight& d)
+static int fill_light(const vr_light& l, DevLight& d, bool allow_extra)
 {
-    VR_REQUIRE(l.type == VR_LIGHT_DIRECTIONAL || l.type == VR_LIGHT_POINT, "only directional and point lights are supported");
-    VR_REQUIRE(l.type != VR_LIGHT_POINT || l.radius == 0.0f, "point lights must be punctual (radius 0)");
+    VR_REQUIRE(l.type == VR_LIGHT_DIRECTIONAL || l.type == VR_LIGHT_POINT || l.type == VR_LIGHT_SPOT, "unknown light type");
+    VR_REQUIRE(allow_extra || (l.type != VR_LIGHT_SPOT && !(l.type == VR_LIGHT_POINT && l.radius > 0.0f)),
+               "the tiled pass takes directional and punctual point lights only");
+    VR_REQUIRE(l.type != VR_LIGHT_SPOT || l.outer_angle > l.inner_angle, "spot light needs outer_angle > inner_angle");
     for (int k = 0; k < 3; k++) { d.dir[k] = l.direction[k]; d.pos[k] = l.position[k]; d.color[k] = l.color[k]; }
     d.type = l.type; d.intensity = l.intensity;
-    d.inv_range = l.type == VR_LIGHT_POINT ? l.angular_size_or_inv_range : 0.0f;
+    d.inv_range = l.type != VR_LIGHT_DIRECTIONAL ? l.angular_size_or_inv_range : 0.0f;
     const double half = l.type == VR_LIGHT_DIRECTIONAL ? 0.5 * (double)l.angular_size_or_inv_range : 0.0;
-    d.cosH = (float)cos(half); d.sinH = (float)sin(half); d.tanH = (float)tan(half); d.pad = 0.0f;
+    d.cosH = (float)cos(half); d.sinH = (float)sin(half); d.tanH = (float)tan(half);
+    d.radius = l.type != VR_LIGHT_DIRECTIONAL ? l.radius : 0.0f;
+    d.inner_angle = l.inner_angle; d.outer_angle = l.outer_angle; d.pad0 = d.pad1 = 0.0f;
     return VR_OK;
 }
 
@@ -293,7 +326,11 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
     for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
     a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h;
     a.num_lights = num_lights;
-    for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], a.lights[i]); if (rc) return rc; }
+    bool extra = false;
+    for (int i = 0; i < num_lights; i++) {
+        int rc = fill_light(lights[i], a.lights[i], true); if (rc) return rc;
+        extra = extra || a.lights[i].type == VR_LIGHT_SPOT || a.lights[i].radius > 0.0f;
+    }
     const size_t npx = (size_t)gb->w * gb->h;
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
     VrKernelScope ks(ctx, VR_K_DEFERRED);
@@ -304,14 +341,17 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
                    "hdr_out is smaller than vr_partition_packed_bytes()");
         VR_REQUIRE(gb->w % 4 == 0, "partitioned frames need a width that is a multiple of 4");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
-        if (ctx->num_owned > 0)
-            hipLaunchKernelGGL(k_deferred<true>, dim3((unsigned)ctx->num_owned * 16), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+        if (ctx->num_owned > 0) {
+            auto kern = extra ? k_deferred<true, true> : k_deferred<true, false>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)ctx->num_owned * 16), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles);
+        }
     } else {
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         if (gb->w % 4 == 0) {
             const size_t quads = npx / 4;
-            hipLaunchKernelGGL(k_deferred<false>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+            auto kern = extra ? k_deferred<false, true> : k_deferred<false, false>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr);
         } else {
             hipLaunchKernelGGL(k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
@@ -500,7 +540,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     }
     if (!ctx->d_flags) { VR_HIP(hipMalloc(&ctx->d_flags, 64)); VR_HIP(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream)); }
     ctx->h_lights.resize((size_t)num_lights);
-    for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i]); if (rc) return rc; }
+    for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i], false); if (rc) return rc; }
     if (num_lights) VR_HIP(hipMemcpyAsync(ctx->d_lights, ctx->h_lights.data(), (size_t)num_lights * sizeof(DevLight), hipMemcpyHostToDevice, ctx->stream));
     DeferredArgs a;
     memset(&a, 0, sizeof(a));

@@ -54,7 +54,8 @@ struct DevLight {
     float dir[3];  int type;
     float pos[3];  float inv_range;
     float color[3]; float intensity;
-    float cosH, sinH, tanH, pad;
+    float cosH, sinH, tanH, radius;   // radius > 0: spherical source (half angle per pixel)
+    float inner_angle, outer_angle, pad0, pad1;   // spot cone (radians)
 };
 
 // Transformed vertex: clip position, world xz and the snapped screen vertex.

@@ -96,13 +96,27 @@ def directional_light(direction, irradiance=1.0, angular_size_deg=0.53, color=(1
     return l
 
 
-def point_light(position, intensity, light_range, color=(1.0, 1.0, 1.0)):
+def point_light(position, intensity, light_range, color=(1.0, 1.0, 1.0), radius=0.0):
+    """PointLight::FillLightConstants: position, radius (0 = punctual), intensity, 1/range."""
     l = Light()
     l.type = capi.VR_LIGHT_POINT
     l.position[:] = [float(x) for x in position]
     l.color[:] = [float(c) for c in color]
     l.intensity = float(intensity)
+    l.radius = float(radius)
     l.angular_size_or_inv_range = float(np.float32(1.0) / np.float32(light_range)) if light_range > 0 else 0.0
+    return l
+
+
+def spot_light(position, direction, intensity, light_range, inner_angle_deg, outer_angle_deg, color=(1.0, 1.0, 1.0), radius=0.0):
+    """SpotLight::FillLightConstants: a point light with a cone (half angles, here in degrees) around `direction`."""
+    l = point_light(position, intensity, light_range, color, radius)
+    l.type = capi.VR_LIGHT_SPOT
+    d = np.asarray(direction, np.float32)
+    d = d / np.float32(np.sqrt(np.float32((d * d).sum())))
+    l.direction[:] = [float(x) for x in d]
+    l.inner_angle = float(np.float32(np.radians(np.float32(inner_angle_deg))))
+    l.outer_angle = float(np.float32(np.radians(np.float32(outer_angle_deg))))
     return l
 
 
