@@ -296,6 +296,7 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
 {
     VR_REQUIRE(t != nullptr, "terrain is NULL");
     VR_HIP(hipSetDevice(t->ctx->device));
+    for (GeoSet& g : t->sets) g.prepared = false;          // geometry prepared with the old bounds is stale
     if (!enable) { t->height_loaded = false; return VR_OK; }
     const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
     const int num_surfaces = t->surfaces_per_side * t->surfaces_per_side;
