@@ -139,7 +139,7 @@ def test_cpp_host_example_compiles_links_and_fails_soft_without_gpu(product_lib,
     if _has_gpu(product_lib):
         assert r.returncode == 0, r.stdout + r.stderr
     else:
-        assert r.returncode == 0 and "no device" in r.stdout, r.stdout + r.stderr
+        assert r.returncode == 0 and "no device" in r.stdout and "no HIP device" in r.stderr, r.stdout + r.stderr
 
 
 def test_header_is_valid_c(tmp_path):
