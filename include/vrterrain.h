@@ -87,7 +87,7 @@ typedef struct vr_instance {
 /* TerrainPass::RenderParams (TerrainPass.h:68-73) + EditorParams::m_MaxHeight
  * (Renderer.h:40, read at TerrainPass.cpp:155). */
 typedef struct vr_render_params {
-    int32_t wireframe;    /* not implemented in this round: returns INVALID_ARGUMENT */
+    int32_t wireframe;    /* EditorParams::m_Wireframe -> RasterFillMode::Wireframe (TerrainPass.cpp:476): triangle edges as aliased lines */
     int32_t lock_view;    /* reuse the previous selection (TerrainPass.cpp:173,191)  */
     int32_t depth_only;   /* PS = null (TerrainPass.cpp:465)                         */
     int32_t assume_cleared; /* extension: 1 = caller guarantees the G-buffer holds its

@@ -645,6 +645,7 @@ typedef struct {
     float* depth; uint32_t* diffuse; uint32_t* specular; uint16_t* normals; uint16_t* emissive;
     const vr_partition* part;
     int depth_only;
+    int wireframe;
 } orc_target;
 
 static int clip_poly(orc_vtx* poly, int n, int plane)
@@ -775,6 +776,77 @@ static inline int owns_pixel(const vr_partition* part, int x, int y)
     return ((x / VR_OWNER_TILE + y / VR_OWNER_TILE) % part->world_size) == part->rank;
 }
 
+/* One covered pixel of a triangle: depth from the triangle's plane at the pixel centre, depth clip,
+ * LessOrEqual test (in draw order), then main_ps.  E1 / E2 are the unbiased edge functions. */
+typedef struct {
+    const orc_terrain* t; orc_target* tg;
+    const orc_sv *s0, *s1, *s2;
+    float inv_area, dz1, dz2;
+} orc_frag_ctx;
+
+static void fragment(const orc_frag_ctx* f, int x, int y, int64_t E1, int64_t E2)
+{
+    orc_target* tg = f->tg;
+    if (!owns_pixel(tg->part, x, y)) return;
+    float l1 = (float)E1 * f->inv_area, l2 = (float)E2 * f->inv_area;
+    float z = (f->s0->z + l1 * f->dz1) + l2 * f->dz2;
+    if (!(z >= 0.0f && z <= 1.0f)) return;                    /* depth clip */
+    size_t idx = (size_t)y * tg->w + x;
+    if (!(z <= tg->depth[idx])) return;                       /* ComparisonFunc::LessOrEqual (TerrainPass.cpp:482) */
+    tg->depth[idx] = z + 0.0f;
+    if (tg->depth_only) return;
+    /* per-pixel steps of E1 = edge(s2,s0) and E2 = edge(s0,s1) */
+    orc_attr p = interp(f->s0, f->s1, f->s2, f->inv_area, E1, E2,
+                        -(int64_t)(f->s0->Y - f->s2->Y) * 256, -(int64_t)(f->s1->Y - f->s0->Y) * 256,
+                        (int64_t)(f->s0->X - f->s2->X) * 256, (int64_t)(f->s1->X - f->s0->X) * 256);
+    pixel_shader(f->t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
+}
+
+static inline int64_t floor_div(int64_t num, int64_t den)
+{
+    if (den < 0) { num = -num; den = -den; }
+    int64_t q = num / den;
+    if (num % den < 0) q--;
+    return q;
+}
+
+/* Aliased line a-b in 24.8 fixed point [DONUT/D3D-RECOLLECTION: stands in for the diamond-exit
+ * rule, whose end-point cases this image has no way to pin].  X-major lines (|dX| >= |dY|) take
+ * one pixel in every column whose centre lies in [min X, max X): the pixel containing the exact
+ * line point at that column centre; Y-major lines likewise per row.  The rule is symmetric in
+ * a <-> b, so two triangles sharing an edge draw the same pixels. */
+static void wire_edge(const orc_frag_ctx* f, const orc_sv* a, const orc_sv* b, int vx0, int vy0, int vx1, int vy1)
+{
+    int64_t dX = (int64_t)b->X - a->X, dY = (int64_t)b->Y - a->Y;
+    if (dX == 0 && dY == 0) return;
+    int64_t adX = dX < 0 ? -dX : dX, adY = dY < 0 ? -dY : dY;
+    if (adX >= adY) {
+        int32_t lo = a->X < b->X ? a->X : b->X, hi = a->X < b->X ? b->X : a->X;
+        int p0 = (lo - 128 + 255) >> 8, p1 = ((hi - 128 + 255) >> 8) - 1;
+        if (p0 < vx0) p0 = vx0;
+        if (p1 > vx1) p1 = vx1;
+        for (int px = p0; px <= p1; px++) {
+            int64_t PX = (int64_t)px * 256 + 128;
+            int64_t py = floor_div((int64_t)a->Y * dX + (PX - a->X) * dY, dX * 256);
+            if (py < vy0 || py > vy1) continue;
+            int64_t PY = py * 256 + 128;
+            fragment(f, px, (int)py, edge_fn(f->s2, f->s0, PX, PY), edge_fn(f->s0, f->s1, PX, PY));
+        }
+    } else {
+        int32_t lo = a->Y < b->Y ? a->Y : b->Y, hi = a->Y < b->Y ? b->Y : a->Y;
+        int p0 = (lo - 128 + 255) >> 8, p1 = ((hi - 128 + 255) >> 8) - 1;
+        if (p0 < vy0) p0 = vy0;
+        if (p1 > vy1) p1 = vy1;
+        for (int py = p0; py <= p1; py++) {
+            int64_t PY = (int64_t)py * 256 + 128;
+            int64_t px = floor_div((int64_t)a->X * dY + (PY - a->Y) * dX, dY * 256);
+            if (px < vx0 || px > vx1) continue;
+            int64_t PX = px * 256 + 128;
+            fragment(f, (int)px, py, edge_fn(f->s2, f->s0, PX, PY), edge_fn(f->s0, f->s1, PX, PY));
+        }
+    }
+}
+
 static void raster_triangle(const orc_terrain* t, const vr_view* view, orc_target* tg,
                             const orc_vtx* a, const orc_vtx* b, const orc_vtx* c)
 {
@@ -790,38 +862,36 @@ static void raster_triangle(const orc_terrain* t, const vr_view* view, orc_targe
     int32_t maxX = s0.X > s1.X ? s0.X : s1.X; if (s2.X > maxX) maxX = s2.X;
     int32_t minY = s0.Y < s1.Y ? s0.Y : s1.Y; if (s2.Y < minY) minY = s2.Y;
     int32_t maxY = s0.Y > s1.Y ? s0.Y : s1.Y; if (s2.Y > maxY) maxY = s2.Y;
-    /* pixels whose centre (px*256+128) lies inside the bounding box */
-    int x0 = (minX - 128 + 255) >> 8, x1 = (maxX - 128) >> 8;
-    int y0 = (minY - 128 + 255) >> 8, y1 = (maxY - 128) >> 8;
     int vx0 = view->viewport_x, vy0 = view->viewport_y;
     int vx1 = vx0 + view->viewport_w - 1, vy1 = vy0 + view->viewport_h - 1;
     if (vx1 > tg->w - 1) vx1 = tg->w - 1;
     if (vy1 > tg->h - 1) vy1 = tg->h - 1;
+    if (vx0 < 0) vx0 = 0;
+    if (vy0 < 0) vy0 = 0;
+    orc_frag_ctx fc = { t, tg, &s0, &s1, &s2, 1.0f / (float)area2, s1.z - s0.z, s2.z - s0.z };
+    if (tg->wireframe) {
+        /* RasterFillMode::Wireframe (TerrainPass.cpp:476): the three edges of every triangle that
+         * survives culling, as aliased lines; each line pixel is shaded as a sample of the
+         * triangle's plane at that pixel centre. */
+        wire_edge(&fc, &s0, &s1, vx0, vy0, vx1, vy1);
+        wire_edge(&fc, &s1, &s2, vx0, vy0, vx1, vy1);
+        wire_edge(&fc, &s2, &s0, vx0, vy0, vx1, vy1);
+        return;
+    }
+    /* pixels whose centre (px*256+128) lies inside the bounding box */
+    int x0 = (minX - 128 + 255) >> 8, x1 = (maxX - 128) >> 8;
+    int y0 = (minY - 128 + 255) >> 8, y1 = (maxY - 128) >> 8;
     if (x0 < vx0) x0 = vx0;
     if (y0 < vy0) y0 = vy0;
     if (x1 > vx1) x1 = vx1;
     if (y1 > vy1) y1 = vy1;
     if (x0 > x1 || y0 > y1) return;
     int b0 = top_left(&s1, &s2) ? 0 : 1, b1 = top_left(&s2, &s0) ? 0 : 1, b2 = top_left(&s0, &s1) ? 0 : 1;
-    float inv_area = 1.0f / (float)area2;
-    float dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
     for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) {
-        if (!owns_pixel(tg->part, x, y)) continue;
         int64_t PX = (int64_t)x * 256 + 128, PY = (int64_t)y * 256 + 128;
         int64_t E0 = edge_fn(&s1, &s2, PX, PY), E1 = edge_fn(&s2, &s0, PX, PY), E2 = edge_fn(&s0, &s1, PX, PY);
         if (E0 - b0 < 0 || E1 - b1 < 0 || E2 - b2 < 0) continue;
-        float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
-        float z = (s0.z + l1 * dz1) + l2 * dz2;
-        if (!(z >= 0.0f && z <= 1.0f)) continue;                  /* depth clip */
-        size_t idx = (size_t)y * tg->w + x;
-        if (!(z <= tg->depth[idx])) continue;                     /* ComparisonFunc::LessOrEqual (TerrainPass.cpp:482) */
-        tg->depth[idx] = z;
-        if (tg->depth_only) continue;
-        /* per-pixel steps of E1 = edge(s2,s0) and E2 = edge(s0,s1) */
-        orc_attr p = interp(&s0, &s1, &s2, inv_area, E1, E2,
-                            -(int64_t)(s0.Y - s2.Y) * 256, -(int64_t)(s1.Y - s0.Y) * 256,
-                            (int64_t)(s0.X - s2.X) * 256, (int64_t)(s1.X - s0.X) * 256);
-        pixel_shader(t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
+        fragment(&fc, x, y, E1, E2);
     }
 }
 
@@ -864,7 +934,7 @@ void orc_gbuffer_clear(int w, int h, float* depth, uint32_t* diffuse, uint32_t* 
 int orc_render(orc_terrain* t, const vr_view* v, const vr_render_params* rp, const vr_partition* part,
                int w, int h, float* depth, uint32_t* diffuse, uint32_t* specular, uint16_t* normals, uint16_t* emissive)
 {
-    orc_target tg = { w, h, depth, diffuse, specular, normals, emissive, part, rp->depth_only };
+    orc_target tg = { w, h, depth, diffuse, specular, normals, emissive, part, rp->depth_only, rp->wireframe };
     int cap = t->p.max_instances;
     vr_instance* inst = (vr_instance*)malloc(sizeof(vr_instance) * cap);
     int n;

@@ -69,10 +69,10 @@ def test_select_node_ids_and_instances_bit_exact(scene_name, request, oracle):
             assert np.array_equal(inst_g, inst_o), cam
 
 
-def _render_both(sc, oracle, gpu_ctx, eye, tgt, w, h, assume_cleared=0, depth_only=0, part=None):
+def _render_both(sc, oracle, gpu_ctx, eye, tgt, w, h, assume_cleared=0, depth_only=0, part=None, wireframe=0):
     ot, tp = sc["ot"], sc["tp"]
     v = vr.make_view(eye, tgt, w, h)
-    rp = vr.default_render_params(400.0, assume_cleared=assume_cleared, depth_only=depth_only)
+    rp = vr.default_render_params(400.0, assume_cleared=assume_cleared, depth_only=depth_only, wireframe=wireframe)
     gb_o = oracle.GBufferHost(w, h)
     n_o = ot.render(v, gb_o, rp, part)
     rt = vr.RenderTargets(gpu_ctx).Init(w, h)
@@ -120,6 +120,27 @@ def test_gbuffer_depth_only(scene256, oracle, gpu_ctx):
     v, gb_o, planes, _, _ = _render_both(scene256, oracle, gpu_ctx, eye, tgt, 320, 200, depth_only=1)
     _assert_gbuffer_equal(gb_o, planes, "depth_only")
     assert not planes["diffuse"].any()
+
+
+@pytest.mark.parametrize("cam_index", [0, 3, 7])
+def test_wireframe_bit_exact(scene256, oracle, gpu_ctx, cam_index):
+    """RasterFillMode::Wireframe (EditorParams::m_Wireframe, TerrainPass.cpp:476)."""
+    eye, tgt = scaled_camera(CAMERAS[cam_index], 256)
+    v, gb_o, planes, n_o, n_g = _render_both(scene256, oracle, gpu_ctx, eye, tgt, 640, 360, wireframe=1)
+    assert n_o == n_g
+    _assert_gbuffer_equal(gb_o, planes, f"wireframe camera {cam_index}")
+    drawn = planes["depth"] < 1.0
+    assert drawn.any() and not drawn.all()
+
+
+def test_wireframe_near_clipped_and_partitioned(scene256, oracle, gpu_ctx):
+    hgt = float(scene256["h"][128 + 3, 128 + 5]) / 255.0 * 400.0
+    eye, tgt = (5.3, hgt + 0.05, 3.2), (60.0, hgt - 5.0, 40.0)
+    v, gb_o, planes, _, _ = _render_both(scene256, oracle, gpu_ctx, eye, tgt, 640, 360, wireframe=1)
+    _assert_gbuffer_equal(gb_o, planes, "wireframe near-plane")
+    part = vr.Partition(1, 2)
+    v, gb_o, planes, _, _ = _render_both(scene256, oracle, gpu_ctx, eye, tgt, 640, 360, wireframe=1, part=part)
+    _assert_gbuffer_equal(gb_o, planes, "wireframe rank 1 of 2")
 
 
 def test_camera_inside_terrain_near_plane_clipping(scene256, oracle, gpu_ctx):

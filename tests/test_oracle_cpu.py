@@ -331,3 +331,27 @@ def test_set_height_known_answers(oracle, t256):
         assert nh[b1, 1] == e1 and nh[b1, 0] == lo + e1
     finally:
         t256.set_height(False)
+
+
+def test_wireframe_structure(oracle, t256):
+    """RasterFillMode::Wireframe: line pixels hug the filled surface and leave the interiors open."""
+    w, h = 480, 270
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v = oracle.view_from_camera(eye, tgt, w, h)
+    fill = oracle.GBufferHost(w, h)
+    t256.render(v, fill, vr.default_render_params(400.0))
+    wire = oracle.GBufferHost(w, h)
+    t256.render(v, wire, vr.default_render_params(400.0, wireframe=1))
+    f, l = fill.depth < 1.0, wire.depth < 1.0
+    assert 0 < l.sum() < f.sum()
+    grown = f.copy()                                   # a line pixel contains a point of a filled triangle's edge
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            grown |= np.roll(np.roll(f, dy, 0), dx, 1)
+    assert not (l & ~grown).any()
+    # a line pixel samples its triangle's plane: the nearest surface there is at most a pixel's slope away
+    both = f & l
+    assert np.median(np.abs(wire.depth[both] - fill.depth[both])) < 1e-5
+    assert (wire.specular[l] == wire.specular[l][0]).all() and not wire.specular[~l].any()
+    # triangles here are only a few pixels across, yet a good part of their interiors stays open
+    assert l[f].mean() < 0.9

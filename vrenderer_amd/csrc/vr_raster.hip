@@ -41,6 +41,7 @@ struct RasterArgs {
     int mirrored;
     int world, rank;                // partition (world <= 1: whole frame)
     int depth_only, assume_cleared;
+    int wireframe;                  // RasterFillMode::Wireframe: triangle edges as aliased lines
     float world_size, inv_world_size;
     int ws_pow2;                    // world_size is a power of two: x / ws == x * (1 / ws) exactly
     uint32_t bin_capacity;
@@ -192,7 +193,7 @@ __device__ __forceinline__ bool is_top_left(int32_t dx, int32_t dy) { return (dy
 // TerrainPass::CreateGraphicsPipeline (TerrainPass.cpp:474-476), and returns edge
 // functions + the pixel bounding box clamped to [bx0..bx1] x [by0..by1].
 __device__ __forceinline__ TriSetup tri_setup(ScreenVert& s0, ScreenVert& s1, ScreenVert& s2, int mirrored,
-                                              int bx0, int by0, int bx1, int by1)
+                                              int bx0, int by0, int bx1, int by1, bool wire = false)
 {
     TriSetup t;
     t.visible = false;
@@ -204,8 +205,13 @@ __device__ __forceinline__ TriSetup tri_setup(ScreenVert& s0, ScreenVert& s1, Sc
     if (!cw) { ScreenVert tmp = s1; s1 = s2; s2 = tmp; area2 = -area2; }
     const int32_t minX = min(s0.X, min(s1.X, s2.X)), maxX = max(s0.X, max(s1.X, s2.X));
     const int32_t minY = min(s0.Y, min(s1.Y, s2.Y)), maxY = max(s0.Y, max(s1.Y, s2.Y));
-    t.x0 = max((minX - 128 + 255) >> 8, bx0); t.x1 = min((maxX - 128) >> 8, bx1);
-    t.y0 = max((minY - 128 + 255) >> 8, by0); t.y1 = min((maxY - 128) >> 8, by1);
+    if (wire) {     // a line pixel is the one that contains the line point, not one whose centre is inside the box
+        t.x0 = max(minX >> 8, bx0); t.x1 = min(maxX >> 8, bx1);
+        t.y0 = max(minY >> 8, by0); t.y1 = min(maxY >> 8, by1);
+    } else {
+        t.x0 = max((minX - 128 + 255) >> 8, bx0); t.x1 = min((maxX - 128) >> 8, bx1);
+        t.y0 = max((minY - 128 + 255) >> 8, by0); t.y1 = min((maxY - 128) >> 8, by1);
+    }
     if (t.x0 > t.x1 || t.y0 > t.y1) return t;
     // edge(a,b)(p) = (bX-aX)*(py-aY) - (bY-aY)*(px-aX)
     t.B0 = s2.X - s1.X; t.A0 = -(s2.Y - s1.Y); t.C0 = -(int64_t)t.B0 * s1.Y - (int64_t)t.A0 * s1.X;
@@ -235,7 +241,7 @@ __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1
 // raster-tile rectangle a triangle touches, or ~0 when it is culled
 __device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2)
 {
-    TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+    TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, a.wireframe != 0);
     if (!t.visible) return ~0ull;
     return pack_rect(t.x0 / kRasterTile, t.y0 / kRasterTile, t.x1 / kRasterTile, t.y1 / kRasterTile);
 }
@@ -666,6 +672,46 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
     }
 }
 
+__device__ __forceinline__ int64_t floor_div64(int64_t num, int64_t den)
+{
+    if (den < 0) { num = -num; den = -den; }
+    int64_t q = num / den;
+    if (num % den < 0) q--;
+    return q;
+}
+
+// Wireframe: aliased line a-b, one pixel per column (x-major) or row (y-major) whose centre lies in
+// [min, max) of the major axis: the pixel that contains the exact line point there.  The pixel is a
+// sample of the triangle's plane at its centre (depth, attributes), so the resolve below is shared
+// with fill mode.  Debug mode: one lane per triangle, no wave cooperation.
+__device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, const ScreenVert& va, const ScreenVert& vb, const TriSetup& t,
+                                        int ox, int oy, int bx0, int by0, int bx1, int by1, uint32_t ord)
+{
+    const int64_t dX = (int64_t)vb.X - va.X, dY = (int64_t)vb.Y - va.Y;
+    if (dX == 0 && dY == 0) return;
+    const bool xmajor = llabs(dX) >= llabs(dY);
+    const int32_t ca = xmajor ? va.X : va.Y, cb = xmajor ? vb.X : vb.Y;
+    const int32_t lo = min(ca, cb), hi = max(ca, cb);
+    const int p0 = max((lo - 128 + 255) >> 8, xmajor ? bx0 : by0), p1 = min(((hi - 128 + 255) >> 8) - 1, xmajor ? bx1 : by1);
+    for (int p = p0; p <= p1; p++) {
+        const int64_t P = (int64_t)p * 256 + 128;
+        int px, py;
+        if (xmajor) {
+            const int64_t q = floor_div64((int64_t)va.Y * dX + (P - va.X) * dY, dX * 256);
+            if (q < by0 || q > by1) continue;
+            px = p; py = (int)q;
+        } else {
+            const int64_t q = floor_div64((int64_t)va.X * dY + (P - va.Y) * dX, dY * 256);
+            if (q < bx0 || q > bx1) continue;
+            px = (int)q; py = p;
+        }
+        const int32_t PX = px * 256 + 128, PY = py * 256 + 128;
+        const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
+        cover_pixel<int64_t>(vis, px - ox, py - oy, E1, E2, 0, 0, t.z0, t.dz1, t.dz2, t.inv_area, ord);
+    }
+}
+
+template <bool WIRE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
@@ -715,7 +761,13 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             uint32_t i0, i1, i2;
             entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
             ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
-            t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1);
+            t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1, WIRE);
+            if (WIRE && t.visible) {
+                wire_edge(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, ~key);
+                wire_edge(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, ~key);
+                wire_edge(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, ~key);
+                t.visible = false;          // covered; skip the fill sweeps
+            }
         }
         valid = valid && t.visible;
         const uint32_t order = ~key;
@@ -786,7 +838,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 uint32_t i0, i1, i2;
                 entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
                 s0 = load_sv(verts, i0); s1 = load_sv(verts, i1); s2 = load_sv(verts, i2);
-                t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1);
+                t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, WIRE);
                 td = tri_derivs(t);
                 prev = low;
             }
@@ -855,7 +907,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     if (a.vy1 > h - 1) a.vy1 = h - 1;
     a.rtx = (w + kRasterTile - 1) / kRasterTile; a.rty = (h + kRasterTile - 1) / kRasterTile;
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
-    a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared;
+    a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared; a.wireframe = rp->wireframe ? 1 : 0;
     a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
     { uint32_t wb; memcpy(&wb, &t->p.world_size, 4); a.ws_pow2 = (wb & 0x7fffffu) == 0u && t->p.world_size >= 1.0f && t->p.world_size <= 65536.0f; }
     a.bin_capacity = (uint32_t)t->bin_capacity;
@@ -925,7 +977,6 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
 static int check_render_inputs(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp)
 {
     VR_REQUIRE(t && view && gb && rp, "NULL argument");
-    VR_REQUIRE(!rp->wireframe, "wireframe fill mode is not implemented");
     VR_REQUIRE(!view->reverse_depth, "reverse depth is not supported (the reference disables it, Renderer.cpp:221)");
     VR_REQUIRE(view->viewport_w > 0 && view->viewport_h > 0 && view->viewport_w <= 16384 && view->viewport_h <= 16384, "bad viewport");
     VR_REQUIRE(gb->ctx == t->ctx, "G-buffer and terrain belong to different contexts");
@@ -969,7 +1020,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     GeoSet& g = t->sets[t->cur ^ 1];
     const GeoSet& last = t->sets[t->cur];
     const bool use_prepared = g.prepared && !rp->lock_view && memcmp(&g.prep_view, view, sizeof(vr_view)) == 0
-                           && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only
+                           && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only && !g.prep_rp.wireframe == !rp->wireframe
                            && g.prep_w == gb->w && g.prep_h == gb->h && g.prep_rank == a.rank && g.prep_world == a.world;
     g.prepared = false;
     if (!use_prepared) {
@@ -986,8 +1037,10 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     t->raster_begin_recorded = true;
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER);
-        hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
-                           g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, whole ? (const int32_t*)nullptr : ctx->d_raster_tiles,
+        const int32_t* tiles = whole ? (const int32_t*)nullptr : ctx->d_raster_tiles;
+        auto kern = a.wireframe ? k_raster<true> : k_raster<false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
+                           g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
     VR_HIP(hipEventRecord(g.ev_raster_done, s));
