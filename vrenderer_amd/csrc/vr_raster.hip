@@ -711,6 +711,28 @@ __device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, con
     }
 }
 
+// Phase clocks for experiments (tools/build_variant.py prof -DVR_RASTER_PROFILE); not in the product build.
+#ifdef VR_RASTER_PROFILE
+constexpr int kProfBlocks = 16384;
+__device__ unsigned long long g_raster_prof[kProfBlocks * 8];
+// every wave's lane 0 adds its phase time to its block's slot (LDS-free, 4 waves per address)
+#define VR_PROF_MARK(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                                 atomicAdd(&g_raster_prof[blockIdx.x * 8 + (i)], now_ - prof_t_); prof_t_ = __builtin_readcyclecounter(); } } while (0)
+#define VR_PROF_BEGIN unsigned long long prof_t_ = __builtin_readcyclecounter()
+extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
+{
+    static unsigned long long host[kProfBlocks * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_raster_prof), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (int b = 0; b < kProfBlocks; b++) for (int i = 0; i < 8; i++) out[i] += host[b * 8 + i];
+    if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_prof), host, sizeof(host)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define VR_PROF_MARK(i) do { } while (0)
+#define VR_PROF_BEGIN do { } while (0)
+#endif
+
 template <bool WIRE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
@@ -728,6 +750,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    VR_PROF_BEGIN;
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
     for (int i = tid; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
@@ -746,6 +769,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         vis[i] = key;
     }
     __syncthreads();
+    VR_PROF_MARK(0);
 
     const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
     const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + kRasterTile - 1, a.vx1), by1 = min(oy + kRasterTile - 1, a.vy1);
@@ -770,6 +794,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             }
         }
         valid = valid && t.visible;
+        VR_PROF_MARK(1);
         const uint32_t order = ~key;
         // tile-relative form
         const int64_t e0 = edge_eval(t.A0, t.B0, t.C0, PX0, PY0), e1 = edge_eval(t.A1, t.B1, t.C1, PX0, PY0), e2 = edge_eval(t.A2, t.B2, t.C2, PX0, PY0);
@@ -788,6 +813,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             else sweep_small<int64_t>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1,
                                       t.z0, t.dz1, t.dz2, t.inv_area, order);
         }
+        VR_PROF_MARK(2);
         // big triangles: broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its bbox
         unsigned long long big = __ballot(valid && !small);
         const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
@@ -813,8 +839,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 #undef BC64
 #undef BC
         }
+        VR_PROF_MARK(3);
     }
     __syncthreads();
+    VR_PROF_MARK(4);
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
     const bool vec_ok = (a.w & 3) == 0;
@@ -879,6 +907,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             }
         }
     }
+    VR_PROF_MARK(5);
 }
 
 // ---------------------------------------------------------------------------------------
