@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, packed tiles, all-gather, de-tile) even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug: all ranks share cuda:0 and the exchange goes through gloo on host copies (RCCL refuses "
+                         "two ranks on one device); exercises the N>1 control flow on a one-GPU box, timings are meaningless")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,10 +120,15 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import vrenderer_amd as vr
     from vrenderer_amd.passes import frame_detile, partition_info, partition_prepare
@@ -194,7 +202,13 @@ def main():
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
-            dist.all_gather_into_tensor(gathered[b], packed[b][:half_elems])      # RCCL over xGMI, equal send counts
+            if args.rehearse_on_one_gpu:
+                comm_stream.synchronize()
+                host = torch.empty(world * half_elems * 2, dtype=torch.uint8)
+                dist.all_gather_into_tensor(host, packed[b][:half_elems].view(torch.uint8).cpu())
+                gathered[b].view(torch.uint8).copy_(host)
+            else:
+                dist.all_gather_into_tensor(gathered[b], packed[b][:half_elems])  # RCCL over xGMI, equal send counts
             frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
             comm_done[b].record(comm_stream)
 
@@ -237,7 +251,7 @@ def main():
             raise SystemExit(f"rank {rank}: assembled frame differs from the unsplit frame")
 
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

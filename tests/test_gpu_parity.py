@@ -645,3 +645,22 @@ def test_deferred_spot_and_spherical_lights(scene256, oracle, gpu_ctx):
         vr.TiledDeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
     hdr.close()
     rt.close()
+
+
+def test_two_rank_frame_split_rehearsal_on_one_gpu():
+    """bench.py's N>1 control flow (tile partition, packed RGB16F tiles, all-gather, de-tile) with two
+    ranks sharing this GPU and gloo standing in for RCCL; every rank compares the assembled frame with
+    its own unsplit render, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--width", "1920", "--height", "1080", "--rehearse-on-one-gpu", "--verify", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["frame_verified_against_unsplit"] is True
