@@ -664,3 +664,45 @@ def test_two_rank_frame_split_rehearsal_on_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["frame_verified_against_unsplit"] is True
+
+
+def _render_view_both(sc, oracle, gpu_ctx, v, w, h, **rpkw):
+    ot, tp = sc["ot"], sc["tp"]
+    rp = vr.default_render_params(400.0, **rpkw)
+    gb_o = oracle.GBufferHost(w, h)
+    ot.render(v, gb_o, rp, None)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    tp.Render(v, v, rt, rp, None)
+    planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+    rt.close()
+    return gb_o, planes
+
+
+@pytest.mark.parametrize("wireframe", [0, 1])
+def test_sub_viewport_inside_a_larger_target(scene256, oracle, gpu_ctx, wireframe):
+    """nvrhi::Viewport smaller than the framebuffer (ViewportState, TerrainPass.cpp:213-216): the view's
+    viewport rectangle positions and clips the image; nothing outside it is touched."""
+    w, h = 640, 360
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v = vr.make_view(eye, tgt, 500, 300)              # projection for a 500x300 viewport ...
+    v.viewport_x, v.viewport_y = 37, 21                # ... placed at (37, 21): cuts through raster tiles on all four sides
+    gb_o, planes = _render_view_both(scene256, oracle, gpu_ctx, v, w, h, wireframe=wireframe)
+    _assert_gbuffer_equal(gb_o, planes, "sub-viewport")
+    inside = np.zeros((h, w), bool)
+    inside[21:321, 37:537] = True
+    assert (planes["depth"][~inside] == 1.0).all() and not planes["diffuse"][~inside].any()
+    assert (planes["depth"][inside] < 1.0).any()
+
+
+def test_guard_band_clipping_of_huge_triangles(scene256, oracle, gpu_ctx):
+    """Looking straight down from half a unit with a 0.01 degree field of view, two triangles fill the
+    frame and their vertices project beyond the +-100 NDC guard band: they go through the clipper."""
+    hgt = float(scene256["h"][128 - 2, 128 + 1]) / 255.0 * 400.0
+    w, h = 512, 288
+    for fov, expect_clip in ((0.01, True), (0.1, False)):
+        v = vr.make_view((1.3, hgt + 0.5, -2.2), (1.32, hgt - 5.0, -2.18), w, h, vfov_deg=fov)
+        gb_o, planes = _render_view_both(scene256, oracle, gpu_ctx, v, w, h)
+        _assert_gbuffer_equal(gb_o, planes, f"guard band, fov {fov}")
+        st = scene256["tp"].render_stats()
+        assert (st["clipped_tris"] > 0) == expect_clip and st["flags"] == 0, st
+        assert (planes["depth"] < 1.0).all()
