@@ -157,7 +157,8 @@ VR_API const char* vr_version(void);
  * the reference's PROFILE_GPU_SCOPE timestamp queries (Profiler.h:55-125,
  * Renderer.cpp:326-437).  Kernel ids: */
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
-       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS, VR_K_COUNT };
+       VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS,
+       VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_COUNT };
 VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
 /* Synchronises the stream; per kernel id: summed milliseconds and launch count since
  * the last enable/collect; resets the samples. */
@@ -272,6 +273,56 @@ VR_API int    vr_partition_prepare(vr_context* ctx, int32_t width, int32_t heigh
  * rebuilds the row-major RGBA16F frame. */
 VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int32_t world_size,
                               vr_image* frame_out);
+
+/* ---- tone mapping to LdrColor ------------------------------- */
+/* donut::render::ToneMappingPass as used by the reference: created with default CreateParameters
+ * (Renderer.cpp:256-257), AdvanceFrame(seconds) (:188-189), SimpleRender(cmd, ToneMappingParameters(),
+ * view, HdrColor) into LdrColor SRGBA8 (:430-431, Renderer.h:81-95).  [DONUT-RECOLLECTION: luminance
+ * histogram (256 bins over log2 luminance, 6-bit fixed-point weights split over two bins) -> average
+ * log luminance between two percentiles -> eye adaptation -> extended Reinhard on luminance.]
+ * Integer results (histogram, SRGBA8 pixels) are bit-exact against the oracle. */
+typedef struct vr_tonemap_params {          /* ToneMappingParameters defaults + CreateParameters' log range */
+    float histogram_low_percentile;         /* 0.8  */
+    float histogram_high_percentile;        /* 0.95 */
+    float eye_adaptation_speed_up;          /* 1.0  */
+    float eye_adaptation_speed_down;        /* 0.5  */
+    float min_adapted_luminance;            /* 0.02 */
+    float max_adapted_luminance;            /* 0.5  */
+    float exposure_bias;                    /* -0.5 */
+    float white_point;                      /* 3.0  */
+    float min_log_luminance;                /* -10  */
+    float max_log_luminance;                /*  4   */
+} vr_tonemap_params;
+#define VR_TONEMAP_BINS 256
+typedef struct vr_tonemap vr_tonemap;       /* the pass object: histogram + adapted-luminance (exposure) buffer */
+VR_API void vr_tonemap_default_params(vr_tonemap_params* out);
+VR_API int  vr_tonemap_create(vr_context* ctx, vr_tonemap** out);
+VR_API void vr_tonemap_destroy(vr_tonemap* tm);
+/* ResetExposure(cmd, initialExposure): adapted luminance := value (0 = "unset": the next ComputeExposure jumps to its target) */
+VR_API int  vr_tonemap_reset_exposure(vr_tonemap* tm, float adapted_luminance);
+VR_API int  vr_tonemap_reset_histogram(vr_tonemap* tm);
+/* AddFrameToHistogram: `hdr` is a row-major RGBA16F frame (part NULL) or the packed RGB16F tiles that
+ * vr_deferred_light wrote for `part` (only this rank's pixels are counted). */
+VR_API int  vr_tonemap_add_frame_to_histogram(vr_tonemap* tm, const vr_tonemap_params* p, vr_image* hdr,
+                                              int32_t width, int32_t height, const vr_partition* part);
+/* Device pointer to the VR_TONEMAP_BINS uint32 bins: with a partition, sum it over the ranks
+ * (ncclAllReduce, ncclUint32, ncclSum) between add_frame_to_histogram and compute_exposure. */
+VR_API void* vr_tonemap_histogram_device_ptr(vr_tonemap* tm);
+VR_API int  vr_tonemap_compute_exposure(vr_tonemap* tm, const vr_tonemap_params* p, float frame_time_seconds);
+/* Render: HdrColor -> LdrColor.  part NULL: row-major SRGBA8 (width*height*4 bytes at ldr_device).
+ * Otherwise packed tiles in, packed RGB8 tiles out (3 B/pixel, alpha is always 255 and is not
+ * exchanged; vr_partition_packed_bytes_ldr); rebuild the frame with vr_frame_detile_ldr. */
+VR_API int  vr_tonemap_render(vr_tonemap* tm, const vr_tonemap_params* p, vr_image* hdr, int32_t width, int32_t height,
+                              void* ldr_device, size_t ldr_capacity_bytes, const vr_partition* part);
+/* SimpleRender = ResetHistogram + AddFrameToHistogram + ComputeExposure + Render on one GPU. */
+VR_API int  vr_tonemap_simple_render(vr_tonemap* tm, const vr_tonemap_params* p, float frame_time_seconds, vr_image* hdr,
+                                     void* ldr_device, size_t ldr_capacity_bytes);
+/* test/IO helpers (synchronous) */
+VR_API int  vr_tonemap_download(vr_tonemap* tm, uint32_t histogram[VR_TONEMAP_BINS], float* adapted_luminance);
+VR_API size_t vr_partition_packed_bytes_ldr(int32_t width, int32_t height, int32_t world_size);
+/* gathered = world_size consecutive packed RGB8 buffers -> row-major SRGBA8 frame (device pointers) */
+VR_API int  vr_frame_detile_ldr(vr_context* ctx, const void* gathered_device, int32_t world_size,
+                                int32_t width, int32_t height, void* ldr_frame_device);
 
 /* ---- synthetic inputs (media/ is absent from the reference checkout;
  * SURVEY §8d): seeded integer-hash fBm heightmap and banded albedo, generated on

@@ -10,7 +10,8 @@ import subprocess
 
 import numpy as np
 
-from vrenderer_amd.capi import (Instance, Light, Partition, RenderParams, TerrainParams, View, VR_MAX_LODS)
+from vrenderer_amd.capi import (Instance, Light, Partition, RenderParams, TerrainParams, TonemapParams, View, VR_MAX_LODS,
+                                VR_TONEMAP_BINS)
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "_build", "libvroracle.so")
@@ -71,6 +72,14 @@ def lib():
     L.orc_linear_to_srgb8.restype = C.c_uint8
     L.orc_linear_to_srgb8.argtypes = [C.c_float]
     L.orc_linear_to_srgb8_batch.argtypes = [vp, C.c_size_t, vp]
+    L.orc_tonemap_histogram.argtypes = [P(TonemapParams), vp, C.c_int, C.c_int, P(Partition), vp]
+    L.orc_tonemap_exposure.restype = C.c_float
+    L.orc_tonemap_exposure.argtypes = [P(TonemapParams), vp, C.c_float, C.c_float]
+    L.orc_tonemap_apply.argtypes = [P(TonemapParams), C.c_float, vp, C.c_int, C.c_int, vp]
+    L.orc_log2_pinned.restype = C.c_float
+    L.orc_log2_pinned.argtypes = [C.c_float]
+    L.orc_exp2_pinned.restype = C.c_float
+    L.orc_exp2_pinned.argtypes = [C.c_float]
     L.orc_time_tree_build.restype = C.c_double
     L.orc_time_tree_build.argtypes = [P(TerrainParams), vp, C.c_int, C.c_int]
     L.orc_time_select.restype = C.c_double
@@ -217,6 +226,41 @@ def deferred(view, gb, lights, amb_top, amb_bottom, f32=False):
     fn(C.byref(view), gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular), _ptr(gb.normals),
        _ptr(gb.emissive), arr, n, _f3(amb_top), _f3(amb_bottom), _ptr(out))
     return out
+
+
+class ToneMapper:
+    """ToneMappingPass state (histogram + adapted luminance) on the host; same call sequence as the product's."""
+
+    def __init__(self):
+        self.hist = np.zeros(VR_TONEMAP_BINS, np.uint32)
+        self.adapted = 0.0
+        self.frame_time = 0.0
+
+    def AdvanceFrame(self, seconds):
+        self.frame_time = float(seconds)
+
+    def ResetHistogram(self):
+        self.hist[:] = 0
+
+    def AddFrameToHistogram(self, params, hdr_u16, part=None):
+        a = np.ascontiguousarray(hdr_u16, np.uint16)
+        lib().orc_tonemap_histogram(C.byref(params), _ptr(a), a.shape[1], a.shape[0],
+                                    C.byref(part) if part is not None else None, _ptr(self.hist))
+
+    def ComputeExposure(self, params):
+        self.adapted = float(lib().orc_tonemap_exposure(C.byref(params), _ptr(self.hist), self.frame_time, self.adapted))
+
+    def Render(self, params, hdr_u16):
+        a = np.ascontiguousarray(hdr_u16, np.uint16)
+        out = np.empty((a.shape[0], a.shape[1], 4), np.uint8)
+        lib().orc_tonemap_apply(C.byref(params), self.adapted, _ptr(a), a.shape[1], a.shape[0], _ptr(out))
+        return out
+
+    def SimpleRender(self, params, hdr_u16):
+        self.ResetHistogram()
+        self.AddFrameToHistogram(params, hdr_u16)
+        self.ComputeExposure(params)
+        return self.Render(params, hdr_u16)
 
 
 def linear_to_srgb8(x):

@@ -1188,6 +1188,109 @@ void orc_synth_albedo(int size, uint32_t seed, const uint8_t* height, uint8_t* o
 }
 
 /* ------------------------------------------------------------------------- */
+/* ToneMappingPass (f3) [DONUT-RECOLLECTION]                                    */
+/* Called as SimpleRender(cmd, ToneMappingParameters(), view, HdrColor)         */
+/* (Renderer.cpp:430-431) on a pass made with default CreateParameters (:256).  */
+/* fp32, fixed operation order, no FMA; log2 / exp2 are pinned polynomials so   */
+/* that the integer results are the same on every implementation.               */
+/* ------------------------------------------------------------------------- */
+float orc_log2_pinned(float x)            /* x > 0, finite, normal; same cubic as the LOD computation */
+{
+    uint32_t bits; memcpy(&bits, &x, 4);
+    int e = (int)((bits >> 23) & 255u) - 127;
+    uint32_t mb = (bits & 0x7fffffu) | 0x3f800000u;
+    float m; memcpy(&m, &mb, 4);
+    float tt = m - 1.0f;
+    float p = tt * (1.4208646f + tt * (-0.57725066f + tt * 0.1563861f));
+    return (float)e + p;
+}
+float orc_exp2_pinned(float x)            /* cubic for 2^frac, exponent by bit construction; x clamped to [-126, 127] */
+{
+    if (!(x == x)) return 0.0f;
+    if (x < -126.0f) x = -126.0f;
+    if (x > 127.0f) x = 127.0f;
+    float n = floorf(x), f = x - n;
+    float p = 1.0f + f * (0.69583356f + f * (0.22606716f + f * 0.07809929f));
+    uint32_t sb = (uint32_t)((int)n + 127) << 23;
+    float s; memcpy(&s, &sb, 4);
+    return p * s;
+}
+static inline float tm_luminance(float r, float g, float b) { return (r * 0.2126f + g * 0.7152f) + b * 0.0722f; }
+static inline float tm_saturate(float v) { if (!(v > 0.0f)) return 0.0f; return v > 1.0f ? 1.0f : v; }
+
+void orc_tonemap_histogram(const vr_tonemap_params* p, const uint16_t* hdr, int w, int h, const vr_partition* part,
+                           uint32_t hist[VR_TONEMAP_BINS])
+{
+    const float scale = 1.0f / (p->max_log_luminance - p->min_log_luminance), bias = (0.0f - p->min_log_luminance) * scale;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        if (!owns_pixel(part, x, y)) continue;
+        const uint16_t* px = hdr + ((size_t)y * w + x) * 4;
+        float lum = tm_luminance(orc_half_to_float(px[0]), orc_half_to_float(px[1]), orc_half_to_float(px[2]));
+        float t;                                        /* saturate(log2(lum) * scale + bias) */
+        uint32_t lb; memcpy(&lb, &lum, 4);
+        if (!(lum > 0.0f)) t = 0.0f;                    /* log2(0) = -inf, negatives and NaN -> 0 */
+        else if ((lb >> 23) == 0u) t = 0.0f;            /* denormal: far below the range */
+        else if ((lb >> 23) == 255u) t = 1.0f;          /* +inf */
+        else t = tm_saturate(orc_log2_pinned(lum) * scale + bias);
+        float hb = t * (float)(VR_TONEMAP_BINS - 1);
+        float lf = floorf(hb);
+        int left = (int)lf;
+        uint32_t rw = (uint32_t)((hb - lf) * 64.0f), lw = 64u - rw;   /* 6-bit fixed-point weights */
+        if (lw != 0u && left < VR_TONEMAP_BINS) hist[left] += lw;
+        if (rw != 0u && left + 1 < VR_TONEMAP_BINS) hist[left + 1] += rw;
+    }
+}
+
+float orc_tonemap_exposure(const vr_tonemap_params* p, const uint32_t hist[VR_TONEMAP_BINS], float frame_time, float old_lum)
+{
+    const float scale = 1.0f / (p->max_log_luminance - p->min_log_luminance), bias = (0.0f - p->min_log_luminance) * scale;
+    uint64_t total = 0;
+    for (int i = 0; i < VR_TONEMAP_BINS; i++) total += hist[i];
+    const float ftotal = (float)total;
+    const float lo = ftotal * p->histogram_low_percentile, hi = ftotal * p->histogram_high_percentile;
+    float running = 0.0f, accum = 0.0f, wsum = 0.0f;
+    for (int i = 0; i < VR_TONEMAP_BINS; i++) {
+        float below = running;
+        running = running + (float)hist[i];
+        float ca = running < lo ? lo : (running > hi ? hi : running);
+        float cb = below < lo ? lo : (below > hi ? hi : below);
+        float wgt = ca - cb;                             /* part of this bin between the two percentiles */
+        float log_lum = ((float)i / (float)(VR_TONEMAP_BINS - 1) - bias) / scale;
+        accum = accum + log_lum * wgt;
+        wsum = wsum + wgt;
+    }
+    float avg_log = wsum > 0.0f ? accum / wsum : p->min_log_luminance;
+    float target = orc_exp2_pinned(avg_log);
+    if (target < p->min_adapted_luminance) target = p->min_adapted_luminance;
+    if (target > p->max_adapted_luminance) target = p->max_adapted_luminance;
+    if (!(old_lum > 0.0f)) return target;                /* unset: jump */
+    float diff = target - old_lum;
+    float speed = diff > 0.0f ? p->eye_adaptation_speed_up : p->eye_adaptation_speed_down;
+    if (!(speed > 0.0f)) return target;
+    float k = (float)(1.0 - exp(-(double)frame_time * (double)speed));
+    return old_lum + diff * k;
+}
+
+void orc_tonemap_apply(const vr_tonemap_params* p, float adapted, const uint16_t* hdr, int w, int h, uint8_t* ldr)
+{
+    const float exposure_scale = exp2f(p->exposure_bias);
+    const float wp_inv2 = 1.0f / (p->white_point * p->white_point);
+    if (!(adapted > 0.0f)) adapted = p->min_adapted_luminance;
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        float c[3] = { orc_half_to_float(hdr[i*4]), orc_half_to_float(hdr[i*4+1]), orc_half_to_float(hdr[i*4+2]) };
+        float src = tm_luminance(c[0], c[1], c[2]);
+        float k = 0.0f;
+        if (src > 0.0f) {
+            float scaled = (exposure_scale * src) / adapted;
+            float mapped = (scaled * (1.0f + scaled * wp_inv2)) / (1.0f + scaled);
+            k = mapped / src;
+        }
+        for (int ch = 0; ch < 3; ch++) ldr[i*4+ch] = orc_linear_to_srgb8(src > 0.0f ? c[ch] * k : 0.0f);   /* SRGBA8 target: saturate + OETF */
+        ldr[i*4+3] = 255;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* CPU baseline timings                                        */
 /* ------------------------------------------------------------------------- */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }

@@ -85,6 +85,18 @@ void   orc_deferred_f32(const vr_view* v, int w, int h,
                     const float amb_top[3], const float amb_bottom[3],
                     float* rgba_out);
 
+/* ToneMappingPass (Renderer.cpp:256-257,430-431) [DONUT-RECOLLECTION].
+ * histogram: adds this frame's (owned) pixels to hist; exposure: returns the new adapted luminance;
+ * apply: RGBA16F -> SRGBA8 (alpha 255). */
+void   orc_tonemap_histogram(const vr_tonemap_params* p, const uint16_t* hdr_rgba16f, int w, int h,
+                             const vr_partition* part, uint32_t hist[VR_TONEMAP_BINS]);
+float  orc_tonemap_exposure(const vr_tonemap_params* p, const uint32_t hist[VR_TONEMAP_BINS],
+                            float frame_time_seconds, float old_adapted_luminance);
+void   orc_tonemap_apply(const vr_tonemap_params* p, float adapted_luminance, const uint16_t* hdr_rgba16f,
+                         int w, int h, uint8_t* ldr_srgba8);
+float  orc_log2_pinned(float x);
+float  orc_exp2_pinned(float x);
+
 /* synthetic inputs */
 void   orc_synth_heightmap(int size, uint32_t seed, uint8_t* out_r8);
 void   orc_synth_albedo(int size, uint32_t seed, const uint8_t* height_r8, uint8_t* out_srgba8);

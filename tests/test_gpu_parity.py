@@ -706,3 +706,83 @@ def test_guard_band_clipping_of_huge_triangles(scene256, oracle, gpu_ctx):
         st = scene256["tp"].render_stats()
         assert (st["clipped_tris"] > 0) == expect_clip and st["flags"] == 0, st
         assert (planes["depth"] < 1.0).all()
+
+
+def _lit_frame(sc, gpu_ctx, cam_index, w, h, part=None, hdr=None):
+    eye, tgt = scaled_camera(CAMERAS[cam_index], sc["size"])
+    v = vr.make_view(eye, tgt, w, h)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    sc["tp"].Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1), part)
+    out = hdr if hdr is not None else vr.HdrImage(gpu_ctx, w, h)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, out, part)
+    rt.close()
+    return out
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (333, 187)])
+def test_tonemap_simple_render_bit_exact(scene256, oracle, gpu_ctx, w, h):
+    """ToneMappingPass::SimpleRender (Renderer.cpp:430-431) over three frames with eye adaptation: histogram,
+    adapted luminance (bit pattern) and SRGBA8 LdrColor equal the oracle's on the same HdrColor input."""
+    p = vr.default_tonemap_params()
+    tm_g, tm_o = vr.ToneMappingPass(gpu_ctx), oracle.ToneMapper()
+    ldr = vr.LdrImage(gpu_ctx, w, h)
+    for frame, cam in enumerate((0, 7, 3)):
+        hdr = _lit_frame(scene256, gpu_ctx, cam, w, h)
+        tm_g.AdvanceFrame(1.0 / 60.0); tm_o.AdvanceFrame(1.0 / 60.0)
+        tm_g.SimpleRender(p, hdr, ldr)
+        want = tm_o.SimpleRender(p, hdr.download())
+        hist, lum = tm_g.download()
+        assert np.array_equal(hist, tm_o.hist), f"frame {frame}: histogram"
+        assert hist.sum() == 64 * w * h
+        assert np.float32(lum).view(np.uint32) == np.float32(tm_o.adapted).view(np.uint32), (frame, lum, tm_o.adapted)
+        got = ldr.download()
+        mis = np.argwhere(got != want)
+        assert mis.size == 0, f"frame {frame}: LDR differs at {len(mis)} bytes, first {mis[:4].tolist()}"
+        assert got[..., :3].max() > 100 and (got[..., 3] == 255).all()
+        hdr.close()
+    ldr.close(); tm_g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tonemap_on_packed_tiles_and_ldr_detile(scene256, oracle, gpu_ctx, world):
+    """N ranks emulated on one GPU: each rank's packed RGB16F tiles -> shared histogram (what the all-reduce
+    produces) -> exposure -> packed RGB8 tiles -> concatenation (the all-gather) -> vr_frame_detile_ldr.
+    The assembled SRGBA8 frame equals the oracle's tone-mapped unsplit frame."""
+    from vrenderer_amd.passes import frame_detile_ldr, partition_info, partition_prepare
+    w, h = 640, 360
+    p = vr.default_tonemap_params()
+    full = _lit_frame(scene256, gpu_ctx, 5, w, h)
+    tm_o = oracle.ToneMapper()
+    want = tm_o.SimpleRender(p, full.download())
+    info = partition_info(w, h, 0, world)
+    rows = (info["packed_bytes"] + 8 * 128 - 1) // (8 * 128)
+    tm = vr.ToneMappingPass(gpu_ctx)
+    tm.ResetHistogram()
+    packed = []
+    for r in range(world):
+        part = vr.Partition(r, world)
+        buf = vr.HdrImage(gpu_ctx, 128, rows)
+        _lit_frame(scene256, gpu_ctx, 5, w, h, part=part, hdr=buf)
+        tm.AddFrameToHistogram(p, buf, w, h, part)             # accumulates: the sum over ranks
+        packed.append(buf)
+    hist, _ = tm.download()
+    assert np.array_equal(hist, tm_o.hist)
+    tm.ComputeExposure(p)
+    gathered = np.zeros(world * info["packed_bytes_ldr"], np.uint8)
+    for r in range(world):
+        out = vr.LdrImage(gpu_ctx, w, h, capacity_bytes=info["packed_bytes_ldr"])
+        tm.Render(p, packed[r], out, w, h, vr.Partition(r, world))
+        gathered[r * info["packed_bytes_ldr"]:(r + 1) * info["packed_bytes_ldr"]] = out.download(info["packed_bytes_ldr"])
+        out.close()
+    g_rows = (gathered.nbytes + 8 * 1024 - 1) // (8 * 1024)
+    g_dev = vr.HdrImage(gpu_ctx, 1024, g_rows)
+    pad = np.zeros(g_rows * 8 * 1024, np.uint8); pad[:gathered.nbytes] = gathered
+    g_dev.upload(pad)
+    frame = vr.LdrImage(gpu_ctx, w, h)
+    partition_prepare(gpu_ctx, w, h, vr.Partition(0, world))
+    frame_detile_ldr(gpu_ctx, g_dev.device_ptr, world, w, h, frame)
+    got = frame.download()
+    mis = np.argwhere(got != want)
+    assert mis.size == 0, f"assembled LDR frame differs at {len(mis)} bytes, first {mis[:4].tolist()}"
+    for b in packed: b.close()
+    g_dev.close(); frame.close(); tm.close(); full.close()

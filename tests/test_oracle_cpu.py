@@ -355,3 +355,59 @@ def test_wireframe_structure(oracle, t256):
     assert (wire.specular[l] == wire.specular[l][0]).all() and not wire.specular[~l].any()
     # triangles here are only a few pixels across, yet a good part of their interiors stays open
     assert l[f].mean() < 0.9
+
+
+def test_tonemap_known_answers(oracle):
+    """ToneMappingPass restatement (f3): closed-form checks of the three stages."""
+    p = vr.default_tonemap_params()
+    L = oracle.lib()
+    # pinned log2 / exp2: accurate enough for 256 bins over 14 stops (bin width 0.055)
+    xs = np.exp2(np.linspace(-12, 6, 2001)).astype(np.float32)
+    assert max(abs(L.orc_log2_pinned(float(x)) - np.log2(float(x))) for x in xs) < 2e-3
+    es = np.linspace(-11, 5, 2001).astype(np.float32)
+    assert max(abs(L.orc_exp2_pinned(float(e)) / 2.0 ** float(e) - 1.0) for e in es) < 2e-4
+    assert L.orc_exp2_pinned(3.0) == 8.0 and L.orc_log2_pinned(0.25) == -2.0
+
+    def frame(values, counts):
+        px = np.concatenate([np.full(c, v, np.float16) for v, c in zip(values, counts)])
+        img = np.zeros((1, px.size, 4), np.float16)
+        img[0, :, :3] = px[:, None]
+        return img.view(np.uint16)
+
+    # uniform mid grey: all weight (64 per pixel) in the two bins around log2(0.18); exposure = its luminance
+    tm = oracle.ToneMapper()
+    g = frame([0.18], [4096])
+    ldr = tm.SimpleRender(p, g)
+    lum = float(np.float16(0.18)) * (0.2126 + 0.7152 + 0.0722)
+    t = (np.log2(lum) + 10.0) / 14.0 * 255.0
+    assert tm.hist.sum() == 64 * 4096 and set(tm.hist.nonzero()[0]) == {int(t), int(t) + 1}
+    assert abs(tm.adapted / lum - 1.0) < 0.02
+    scaled = 2.0 ** -0.5 * lum / tm.adapted
+    mapped = scaled * (1 + scaled / 9.0) / (1 + scaled)
+    srgb = 1.055 * mapped ** (1 / 2.4) - 0.055
+    assert abs(int(ldr[0, 0, 0]) - srgb * 255.0) <= 1.0 and (ldr[..., 3] == 255).all()
+    assert (ldr[..., 0] == ldr[..., 1]).all() and (ldr[..., 1] == ldr[..., 2]).all()
+
+    # percentile window [0.8, 0.95]: 90 % of the pixels at 0.1, 10 % at 10 -> 2/3 of the window is dark, 1/3 bright
+    tm = oracle.ToneMapper()
+    tm.SimpleRender(p, frame([0.1, 10.0], [9000, 1000]))
+    expect = 2.0 ** ((2.0 / 3.0) * np.log2(0.1) + (1.0 / 3.0) * np.log2(10.0))
+    assert abs(tm.adapted / expect - 1.0) < 0.05
+    # clamps: a black frame adapts to the minimum, a very bright one to the maximum
+    tm = oracle.ToneMapper(); tm.SimpleRender(p, frame([0.0], [256])); assert tm.adapted == pytest.approx(0.02)
+    tm = oracle.ToneMapper(); tm.SimpleRender(p, frame([100.0], [256])); assert tm.adapted == pytest.approx(0.5)
+
+    # eye adaptation: the first frame jumps, later frames move by (1 - exp(-dt * speed)) of the gap
+    tm = oracle.ToneMapper()
+    tm.AdvanceFrame(1.0 / 60.0)
+    tm.SimpleRender(p, frame([0.05], [1024])); a0 = tm.adapted
+    tm.SimpleRender(p, frame([0.4], [1024])); a1 = tm.adapted
+    target = float(np.float16(0.4))
+    assert a0 < a1 < target
+    assert abs((a1 - a0) / (target - a0) - (1 - np.exp(-1.0 / 60.0 * 1.0))) < 2e-3      # brighter: eyeAdaptationSpeedUp = 1
+    tm.SimpleRender(p, frame([0.05], [1024])); a2 = tm.adapted
+    assert abs((a1 - a2) / (a1 - a0) - (1 - np.exp(-1.0 / 60.0 * 0.5))) < 2e-2         # darker: speedDown = 0.5
+    # black pixels stay black, inf saturates
+    img = np.zeros((1, 2, 4), np.float16); img[0, 1, :3] = np.inf
+    out = oracle.ToneMapper().SimpleRender(p, img.view(np.uint16))
+    assert out[0, 0].tolist() == [0, 0, 0, 255] and out[0, 1, 3] == 255

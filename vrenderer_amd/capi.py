@@ -20,7 +20,8 @@ VR_ERR_HIP = 6
 VR_LIGHT_DIRECTIONAL = 1
 VR_LIGHT_SPOT = 2
 VR_LIGHT_POINT = 3
-VR_K_COUNT = 12
+VR_K_COUNT = 16
+VR_TONEMAP_BINS = 256
 VR_OPT_ASYNC_GEOMETRY = 1
 
 
@@ -100,6 +101,13 @@ class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world_size", C.c_int32)]
 
 
+class TonemapParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "histogram_low_percentile", "histogram_high_percentile", "eye_adaptation_speed_up", "eye_adaptation_speed_down",
+        "min_adapted_luminance", "max_adapted_luminance", "exposure_bias", "white_point", "min_log_luminance",
+        "max_log_luminance")]
+
+
 assert C.sizeof(Instance) == 112
 assert C.sizeof(Light) == 64
 
@@ -115,7 +123,10 @@ EXPORTS = [
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_partition_num_tiles",
-    "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_render_stats",
+    "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile",
+    "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
+    "vr_tonemap_add_frame_to_histogram", "vr_tonemap_histogram_device_ptr", "vr_tonemap_compute_exposure", "vr_tonemap_render",
+    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_render_stats",
 ]
 
 _lib = None
@@ -189,6 +200,19 @@ def load_library():
         "vr_partition_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
         "vr_partition_prepare": (C.c_int, [vp, C.c_int32, C.c_int32, P(Partition)]),
         "vr_frame_detile": (C.c_int, [vp, vp, C.c_int32, vp]),
+        "vr_tonemap_default_params": (None, [P(TonemapParams)]),
+        "vr_tonemap_create": (C.c_int, [vp, P(vp)]),
+        "vr_tonemap_destroy": (None, [vp]),
+        "vr_tonemap_reset_exposure": (C.c_int, [vp, C.c_float]),
+        "vr_tonemap_reset_histogram": (C.c_int, [vp]),
+        "vr_tonemap_add_frame_to_histogram": (C.c_int, [vp, P(TonemapParams), vp, C.c_int32, C.c_int32, P(Partition)]),
+        "vr_tonemap_histogram_device_ptr": (vp, [vp]),
+        "vr_tonemap_compute_exposure": (C.c_int, [vp, P(TonemapParams), C.c_float]),
+        "vr_tonemap_render": (C.c_int, [vp, P(TonemapParams), vp, C.c_int32, C.c_int32, vp, C.c_size_t, P(Partition)]),
+        "vr_tonemap_simple_render": (C.c_int, [vp, P(TonemapParams), C.c_float, vp, vp, C.c_size_t]),
+        "vr_tonemap_download": (C.c_int, [vp, P(C.c_uint32), P(C.c_float)]),
+        "vr_partition_packed_bytes_ldr": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+        "vr_frame_detile_ldr": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
         "vr_synth_heightmap": (C.c_int, [vp, C.c_int32, C.c_uint32, vp]),
         "vr_synth_albedo": (C.c_int, [vp, C.c_int32, C.c_uint32, vp, vp]),
         "vr_debug_srgb_encode": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -201,6 +201,100 @@ class HdrImage:
             self.handle = None
 
 
+class LdrImage:
+    """LdrColor, SRGBA8_UNORM (Renderer.h:81-92): width*height*4 bytes of device memory (held in a vr_image
+    that is only used as a raw allocation), or packed RGB8 tiles when used as a multi-GPU send buffer."""
+
+    def __init__(self, ctx, width, height, external_ptr=None, capacity_bytes=None):
+        self.ctx, self.width, self.height = ctx, width, height
+        self.capacity = capacity_bytes if capacity_bytes is not None else width * height * 4
+        self._img = None
+        if external_ptr:
+            self._ptr = external_ptr
+        else:
+            rows = (self.capacity + 8 * 1024 - 1) // (8 * 1024)
+            self._img = HdrImage(ctx, 1024, max(1, rows))
+            self._ptr = self._img.device_ptr
+
+    @property
+    def device_ptr(self):
+        return self._ptr
+
+    def download(self, nbytes=None):
+        assert self._img is not None, "download is only available for library-owned LDR images"
+        n = nbytes if nbytes is not None else self.width * self.height * 4
+        raw = self._img.download(nbytes=(n + 1) // 2 * 2).view(np.uint8)[:n]
+        return raw.reshape(self.height, self.width, 4) if nbytes is None else raw
+
+    def close(self):
+        if self._img is not None:
+            self._img.close()
+            self._img = None
+
+
+def default_tonemap_params(**kw):
+    """ToneMappingParameters() + the log-luminance range of ToneMappingPass::CreateParameters (Renderer.cpp:256,431)."""
+    p = capi.TonemapParams()
+    capi.load_library().vr_tonemap_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class ToneMappingPass:
+    """donut::render::ToneMappingPass as the reference drives it (Renderer.cpp:188-189,256-257,430-431)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(ctx.lib.vr_tonemap_create(ctx.handle, C.byref(h)), "vr_tonemap_create")
+        self.handle = h
+        self.frame_time = 0.0
+
+    def AdvanceFrame(self, seconds):
+        self.frame_time = float(seconds)
+
+    def ResetExposure(self, adapted_luminance=0.0):
+        check(self.ctx.lib.vr_tonemap_reset_exposure(self.handle, adapted_luminance), "vr_tonemap_reset_exposure")
+
+    def ResetHistogram(self):
+        check(self.ctx.lib.vr_tonemap_reset_histogram(self.handle), "vr_tonemap_reset_histogram")
+
+    def AddFrameToHistogram(self, params, hdr, width=None, height=None, partition=None):
+        check(self.ctx.lib.vr_tonemap_add_frame_to_histogram(
+            self.handle, C.byref(params), hdr.handle, width or hdr.width, height or hdr.height,
+            C.byref(partition) if partition is not None else None), "vr_tonemap_add_frame_to_histogram")
+
+    @property
+    def histogram_device_ptr(self):
+        return self.ctx.lib.vr_tonemap_histogram_device_ptr(self.handle)
+
+    def ComputeExposure(self, params):
+        check(self.ctx.lib.vr_tonemap_compute_exposure(self.handle, C.byref(params), self.frame_time), "vr_tonemap_compute_exposure")
+
+    def Render(self, params, hdr, ldr, width=None, height=None, partition=None):
+        check(self.ctx.lib.vr_tonemap_render(
+            self.handle, C.byref(params), hdr.handle, width or hdr.width, height or hdr.height, C.c_void_p(ldr.device_ptr),
+            ldr.capacity, C.byref(partition) if partition is not None else None), "vr_tonemap_render")
+
+    def SimpleRender(self, params, hdr, ldr):
+        """ResetHistogram + AddFrameToHistogram + ComputeExposure + Render (one GPU)."""
+        check(self.ctx.lib.vr_tonemap_simple_render(self.handle, C.byref(params), self.frame_time, hdr.handle,
+                                                    C.c_void_p(ldr.device_ptr), ldr.capacity), "vr_tonemap_simple_render")
+
+    def download(self):
+        hist = np.zeros(capi.VR_TONEMAP_BINS, np.uint32)
+        lum = C.c_float()
+        check(self.ctx.lib.vr_tonemap_download(self.handle, hist.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(lum)),
+              "vr_tonemap_download")
+        return hist, float(lum.value)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.vr_tonemap_destroy(self.handle)
+            self.handle = None
+
+
 class TerrainPass:
     """vRenderer::TerrainPass + its QuadTree (TerrainPass.h:32-159, QuadTree.h:64-127)."""
 
@@ -356,11 +450,17 @@ def partition_info(width, height, rank, world):
     check(lib.vr_partition_num_tiles(width, height, C.byref(p), C.byref(tx), C.byref(ty), C.byref(owned), C.byref(mo)),
           "vr_partition_num_tiles")
     return dict(tiles_x=tx.value, tiles_y=ty.value, owned=owned.value, max_owned=mo.value,
-                packed_bytes=lib.vr_partition_packed_bytes(width, height, world))
+                packed_bytes=lib.vr_partition_packed_bytes(width, height, world),
+                packed_bytes_ldr=lib.vr_partition_packed_bytes_ldr(width, height, world))
 
 
 def partition_prepare(ctx, width, height, partition):
     check(ctx.lib.vr_partition_prepare(ctx.handle, width, height, C.byref(partition)), "vr_partition_prepare")
+
+
+def frame_detile_ldr(ctx, gathered_ptr, world, width, height, ldr):
+    check(ctx.lib.vr_frame_detile_ldr(ctx.handle, C.c_void_p(gathered_ptr), world, width, height, C.c_void_p(ldr.device_ptr)),
+          "vr_frame_detile_ldr")
 
 
 def frame_detile(ctx, gathered_ptr, world, frame):
