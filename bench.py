@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, packed tiles, all-gather, de-tile) even with one rank")
+    ap.add_argument("--exchange", choices=["ldr", "hdr"], default="ldr",
+                    help="N>1: what the all-gather carries. ldr (default): each rank tone-maps its tiles (ToneMappingPass, "
+                         "histogram all-reduced over the ranks) and RGB8 tiles are gathered, 3 B/px; hdr: RGB16F tiles, 6 B/px")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share cuda:0 and the exchange goes through gloo on host copies (RCCL refuses "
                          "two ranks on one device); exercises the N>1 control flow on a one-GPU box, timings are meaningless")
@@ -131,7 +134,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import vrenderer_amd as vr
-    from vrenderer_amd.passes import frame_detile, partition_info, partition_prepare
+    from vrenderer_amd.passes import frame_detile, frame_detile_ldr, partition_info, partition_prepare
     from tests.common import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
 
     W, H, size = args.width, args.height, args.size
@@ -169,7 +172,24 @@ def main():
         else:
             comm_stream = main_stream
         partition_prepare(ctx_comm, W, H, part)
-        frame = vr.HdrImage(ctx_comm, W, H)
+        ldr = args.exchange == "ldr"
+        if ldr:
+            # f3: the frame leaves each rank tone-mapped (Renderer.cpp:430-431); all of it runs on the exchange stream
+            tmp = vr.default_tonemap_params()
+            tm = vr.ToneMappingPass(ctx_comm)
+            tm.AdvanceFrame(1.0 / 60.0)
+
+            class _DevArray:        # the pass's 256 histogram bins as a tensor for the all-reduce
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+            hist_t = torch.as_tensor(_DevArray(tm.histogram_device_ptr, 256), device="cuda")
+            ldr_bytes = info["packed_bytes_ldr"]
+            packed_ldr = [torch.empty(ldr_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+            ldr_bufs = [vr.LdrImage(ctx_comm, W, H, external_ptr=t.data_ptr(), capacity_bytes=ldr_bytes) for t in packed_ldr]
+            gathered_ldr = [torch.empty(world * ldr_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+            frame = vr.LdrImage(ctx_comm, W, H)
+        else:
+            frame = vr.HdrImage(ctx_comm, W, H)
         render_done = [torch.cuda.Event() for _ in range(nbuf)]
         comm_done = [torch.cuda.Event() for _ in range(nbuf)]
         from vrenderer_amd import partition as pt
@@ -184,6 +204,24 @@ def main():
         return (DEFAULT_EYE, DEFAULT_TARGET) if args.fixed_camera else flythrough_camera(i)
 
     views = [vr.make_view(*camera(i), W, H) for i in range(120)]
+
+    def allgather(dst_u8, src_u8):
+        if args.rehearse_on_one_gpu:
+            comm_stream.synchronize()
+            host = torch.empty(dst_u8.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, src_u8.cpu())
+            dst_u8.copy_(host)
+        else:
+            dist.all_gather_into_tensor(dst_u8, src_u8)                    # RCCL over xGMI, equal send counts
+
+    def allreduce(t_i32):
+        if args.rehearse_on_one_gpu:
+            comm_stream.synchronize()
+            host = t_i32.cpu()
+            dist.all_reduce(host)
+            t_i32.copy_(host)
+        else:
+            dist.all_reduce(t_i32)
 
     def step(i):
         v, vnext = views[i % 120], views[(i + 1) % 120]
@@ -202,14 +240,17 @@ def main():
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
-            if args.rehearse_on_one_gpu:
-                comm_stream.synchronize()
-                host = torch.empty(world * half_elems * 2, dtype=torch.uint8)
-                dist.all_gather_into_tensor(host, packed[b][:half_elems].view(torch.uint8).cpu())
-                gathered[b].view(torch.uint8).copy_(host)
+            if ldr:
+                tm.ResetHistogram()
+                tm.AddFrameToHistogram(tmp, hdr_bufs[b], W, H, part)       # this rank's pixels
+                allreduce(hist_t)                                          # the real exchange step of f3: 1 KiB
+                tm.ComputeExposure(tmp)
+                tm.Render(tmp, hdr_bufs[b], ldr_bufs[b], W, H, part)       # packed RGB16F tiles -> packed RGB8 tiles
+                allgather(gathered_ldr[b], packed_ldr[b])
+                frame_detile_ldr(ctx_comm, gathered_ldr[b].data_ptr(), world, W, H, frame)
             else:
-                dist.all_gather_into_tensor(gathered[b], packed[b][:half_elems])  # RCCL over xGMI, equal send counts
-            frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
+                allgather(gathered[b].view(torch.uint8), packed[b][:half_elems].view(torch.uint8))
+                frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
             comm_done[b].record(comm_stream)
 
     def sync():
@@ -240,12 +281,26 @@ def main():
 
     verified = None
     if args.verify:
-        last = views[(args.warmup + args.steps - 1) % 120]
+        idx = args.warmup + args.steps - 1
+        if use_dist and ldr:
+            tm.ResetExposure(0.0)       # the adapted luminance has a history; restart it for the comparison frame
+            idx += 1
+            step(idx)
+            sync()
+        last = views[idx % 120]
         got = frame.download()
         ref_img = vr.HdrImage(ctx, W, H)
         tp.Render(last, last, rt, rp, None)
         deferred.Render(last, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, ref_img, None)
-        verified = bool(np.array_equal(got, ref_img.download()))
+        if use_dist and ldr:
+            tm_ref = vr.ToneMappingPass(ctx)
+            tm_ref.AdvanceFrame(1.0 / 60.0)
+            ldr_ref = vr.LdrImage(ctx, W, H)
+            tm_ref.SimpleRender(tmp, ref_img, ldr_ref)
+            verified = bool(np.array_equal(got, ldr_ref.download()))
+            ldr_ref.close(); tm_ref.close()
+        else:
+            verified = bool(np.array_equal(got, ref_img.download()))
         ref_img.close()
         if not verified:
             raise SystemExit(f"rank {rank}: assembled frame differs from the unsplit frame")
@@ -291,7 +346,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
-                                   + ("+all-gather+detile" if use_dist else ""),
+                                   + (("+tone map (histogram all-reduce)+all-gather of RGB8 tiles+detile" if ldr else
+                                       "+all-gather of RGB16F tiles+detile") if use_dist else ""),
                        "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,
                        "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"
                                       + (", all-gather of frame i overlapped with rendering of frame i+1" if use_dist and not args.no_overlap else "")},

@@ -8,6 +8,7 @@
 //                                                                      ClearSelectedNodes, GetNumLods, GetLodRanges)
 //   vRenderer::RenderTargets    source/Renderer.h:50-110              (Init, Clear, IsUpdateRequired)
 //   DeferredLightingPass        as called at source/Renderer.cpp:239-240,417-428 (Render(view, Inputs))
+//   ToneMappingPass             as called at source/Renderer.cpp:188-189,256-257,430-431 (AdvanceFrame, SimpleRender)
 // Like the reference, nothing here throws: methods return bool / log through a callback
 // (donut::log in the reference, TerrainPass.cpp:224-227, QuadTree.cpp:39).
 #pragma once
@@ -65,15 +66,27 @@ namespace vRenderer
     {
         vr_gbuffer* m_GBuffer = nullptr;
         vr_image* m_Hdr = nullptr;
+        vr_image* m_LdrStorage = nullptr;          // LdrColor SRGBA8: width*height*4 bytes, held in a vr_image used as a raw allocation
         int m_Width = 0, m_Height = 0;
+        void Release() { vr_image_destroy(m_LdrStorage); vr_image_destroy(m_Hdr); vr_gbuffer_destroy(m_GBuffer); m_LdrStorage = m_Hdr = nullptr; m_GBuffer = nullptr; }
     public:
-        ~RenderTargets() { vr_image_destroy(m_Hdr); vr_gbuffer_destroy(m_GBuffer); }
+        ~RenderTargets() { Release(); }
         bool Init(Device& device, int width, int height)
         {
-            vr_image_destroy(m_Hdr); vr_gbuffer_destroy(m_GBuffer); m_Hdr = nullptr; m_GBuffer = nullptr;
+            Release();
             m_Width = width; m_Height = height;
             return Check(vr_gbuffer_create(device.Get(), width, height, &m_GBuffer), "vr_gbuffer_create")
-                && Check(vr_image_create(device.Get(), width, height, nullptr, &m_Hdr), "vr_image_create");
+                && Check(vr_image_create(device.Get(), width, height, nullptr, &m_Hdr), "vr_image_create")
+                && Check(vr_image_create(device.Get(), (width + 1) / 2, height, nullptr, &m_LdrStorage), "vr_image_create");
+        }
+        void* LdrColor() const { return vr_image_device_ptr(m_LdrStorage); }                 // Renderer.h:81-92
+        size_t LdrColorBytes() const { return (size_t)m_Width * (size_t)m_Height * 4; }
+        bool DownloadLdrColor(std::vector<uint8_t>& out) const
+        {
+            out.resize((size_t)((m_Width + 1) / 2) * (size_t)m_Height * 8);
+            const bool ok = Check(vr_image_download(m_LdrStorage, out.data(), out.size()), "vr_image_download");
+            out.resize(LdrColorBytes());
+            return ok;
         }
         [[nodiscard]] bool IsUpdateRequired(int width, int height) const { return width != m_Width || height != m_Height; }
         void Clear() { Check(vr_gbuffer_clear(m_GBuffer), "vr_gbuffer_clear"); }            // Renderer.cpp:382
@@ -206,5 +219,39 @@ namespace vRenderer
                                            inputs.ambientColorTop, inputs.ambientColorBottom, inputs.output, partition),
                          "vr_deferred_light");
         }
+    };
+
+    // donut::render::ToneMappingPass as used at Renderer.cpp:188-189,256-257,430-431
+    class ToneMappingPass
+    {
+        vr_tonemap* m_Pass = nullptr;
+        float m_FrameTime = 0.0f;
+    public:
+        struct ToneMappingParameters : vr_tonemap_params { ToneMappingParameters() { vr_tonemap_default_params(this); } };
+        explicit ToneMappingPass(Device& device) { Check(vr_tonemap_create(device.Get(), &m_Pass), "vr_tonemap_create"); }
+        ~ToneMappingPass() { vr_tonemap_destroy(m_Pass); }
+        ToneMappingPass(const ToneMappingPass&) = delete;
+        ToneMappingPass& operator=(const ToneMappingPass&) = delete;
+        void AdvanceFrame(float frameTime) { m_FrameTime = frameTime; }                      // Renderer.cpp:188-189
+        bool ResetExposure(float initialExposure = 0.0f) { return Check(vr_tonemap_reset_exposure(m_Pass, initialExposure), "vr_tonemap_reset_exposure"); }
+        bool ResetHistogram() { return Check(vr_tonemap_reset_histogram(m_Pass), "vr_tonemap_reset_histogram"); }
+        bool AddFrameToHistogram(const ToneMappingParameters& params, RenderTargets& targets)
+        {
+            return Check(vr_tonemap_add_frame_to_histogram(m_Pass, &params, targets.HdrColor(), targets.Width(), targets.Height(), nullptr),
+                         "vr_tonemap_add_frame_to_histogram");
+        }
+        bool ComputeExposure(const ToneMappingParameters& params) { return Check(vr_tonemap_compute_exposure(m_Pass, &params, m_FrameTime), "vr_tonemap_compute_exposure"); }
+        bool Render(const ToneMappingParameters& params, RenderTargets& targets)
+        {
+            return Check(vr_tonemap_render(m_Pass, &params, targets.HdrColor(), targets.Width(), targets.Height(), targets.LdrColor(),
+                                           targets.LdrColorBytes(), nullptr), "vr_tonemap_render");
+        }
+        // SimpleRender(commandList, params, compositeView, sourceTexture) (Renderer.cpp:431)
+        bool SimpleRender(const ToneMappingParameters& params, RenderTargets& targets)
+        {
+            return Check(vr_tonemap_simple_render(m_Pass, &params, m_FrameTime, targets.HdrColor(), targets.LdrColor(), targets.LdrColorBytes()),
+                         "vr_tonemap_simple_render");
+        }
+        vr_tonemap* Get() const { return m_Pass; }
     };
 } // namespace vRenderer

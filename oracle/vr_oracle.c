@@ -1241,24 +1241,29 @@ void orc_tonemap_histogram(const vr_tonemap_params* p, const uint16_t* hdr, int 
     }
 }
 
+/* Written so that 256 lanes can evaluate it with the identical result: the running totals are exact
+ * integer prefix sums (rounded to float once), and the two 256-term float sums are pairwise
+ * (stride-halving) reductions in a fixed order. */
 float orc_tonemap_exposure(const vr_tonemap_params* p, const uint32_t hist[VR_TONEMAP_BINS], float frame_time, float old_lum)
 {
     const float scale = 1.0f / (p->max_log_luminance - p->min_log_luminance), bias = (0.0f - p->min_log_luminance) * scale;
-    uint64_t total = 0;
-    for (int i = 0; i < VR_TONEMAP_BINS; i++) total += hist[i];
-    const float ftotal = (float)total;
+    uint64_t prefix[VR_TONEMAP_BINS + 1];
+    prefix[0] = 0;
+    for (int i = 0; i < VR_TONEMAP_BINS; i++) prefix[i + 1] = prefix[i] + hist[i];
+    const float ftotal = (float)prefix[VR_TONEMAP_BINS];
     const float lo = ftotal * p->histogram_low_percentile, hi = ftotal * p->histogram_high_percentile;
-    float running = 0.0f, accum = 0.0f, wsum = 0.0f;
+    float acc[VR_TONEMAP_BINS], wgt[VR_TONEMAP_BINS];
     for (int i = 0; i < VR_TONEMAP_BINS; i++) {
-        float below = running;
-        running = running + (float)hist[i];
+        float below = (float)prefix[i], running = (float)prefix[i + 1];
         float ca = running < lo ? lo : (running > hi ? hi : running);
         float cb = below < lo ? lo : (below > hi ? hi : below);
-        float wgt = ca - cb;                             /* part of this bin between the two percentiles */
+        wgt[i] = ca - cb;                                /* part of this bin between the two percentiles */
         float log_lum = ((float)i / (float)(VR_TONEMAP_BINS - 1) - bias) / scale;
-        accum = accum + log_lum * wgt;
-        wsum = wsum + wgt;
+        acc[i] = log_lum * wgt[i];
     }
+    for (int stride = VR_TONEMAP_BINS / 2; stride >= 1; stride >>= 1)
+        for (int i = 0; i < stride; i++) { acc[i] = acc[i] + acc[i + stride]; wgt[i] = wgt[i] + wgt[i + stride]; }
+    float accum = acc[0], wsum = wgt[0];
     float avg_log = wsum > 0.0f ? accum / wsum : p->min_log_luminance;
     float target = orc_exp2_pinned(avg_log);
     if (target < p->min_adapted_luminance) target = p->min_adapted_luminance;
@@ -1276,14 +1281,15 @@ void orc_tonemap_apply(const vr_tonemap_params* p, float adapted, const uint16_t
     const float exposure_scale = exp2f(p->exposure_bias);
     const float wp_inv2 = 1.0f / (p->white_point * p->white_point);
     if (!(adapted > 0.0f)) adapted = p->min_adapted_luminance;
+    const float inv_adapted = 1.0f / adapted;
     for (size_t i = 0; i < (size_t)w * h; i++) {
         float c[3] = { orc_half_to_float(hdr[i*4]), orc_half_to_float(hdr[i*4+1]), orc_half_to_float(hdr[i*4+2]) };
         float src = tm_luminance(c[0], c[1], c[2]);
         float k = 0.0f;
         if (src > 0.0f) {
-            float scaled = (exposure_scale * src) / adapted;
-            float mapped = (scaled * (1.0f + scaled * wp_inv2)) / (1.0f + scaled);
-            k = mapped / src;
+            /* mapped = scaled (1 + scaled / white^2) / (1 + scaled);  k = mapped / src, as one division */
+            float scaled = (exposure_scale * src) * inv_adapted;
+            k = (scaled * (1.0f + scaled * wp_inv2)) / ((1.0f + scaled) * src);
         }
         for (int ch = 0; ch < 3; ch++) ldr[i*4+ch] = orc_linear_to_srgb8(src > 0.0f ? c[ch] * k : 0.0f);   /* SRGBA8 target: saturate + OETF */
         ldr[i*4+3] = 255;

@@ -1,6 +1,6 @@
 // A frame through the C++ host mirror (include/vrterrain.hpp), written the way the reference's
 // Renderer drives the path: Renderer::Renderer (Renderer.cpp:51-66,97), RenderScene (:207-224),
-// RecordCommand (:382, :401-415, :417-428).  Compiled with g++ by tests/test_abi_cpu.py (the header
+// RecordCommand (:382, :401-415, :417-428, :430-431).  Compiled with g++ by tests/test_abi_cpu.py (the header
 // is valid C++ and the library links) and run on the GPU box by tests/test_gpu_parity.py.
 #include <vrterrain.hpp>
 
@@ -69,6 +69,9 @@ int main(int argc, char** argv)
         deferredInputs.lights = &lights;
         if (!deferredLightingPass.Render(view, deferredInputs)) return 2;
     }
+    ToneMappingPass toneMappingPass(device);                                       // CreateRenderPasses, :256-257
+    toneMappingPass.AdvanceFrame(1.0f / 60.0f);                                    // Animate, :188-189
+    if (!toneMappingPass.SimpleRender(ToneMappingPass::ToneMappingParameters(), renderTargets)) return 2;   // :430-431
     terrainPass.UpdateNumChunks(editorParams);                                     // ImGui "Num instances" (Renderer.cpp:468)
 
     // QuadTree facade: the selection the frame used, in m_SelectedNodes order
@@ -80,11 +83,13 @@ int main(int argc, char** argv)
     std::vector<float> depth((size_t)width * height);
     if (!Check(vr_image_download(renderTargets.HdrColor(), hdr.data(), hdr.size() * 2), "vr_image_download")) return 2;
     if (!Check(vr_gbuffer_download(renderTargets.GBufferFramebuffer(), 0, depth.data(), depth.size() * 4), "vr_gbuffer_download")) return 2;
-    size_t covered = 0, lit = 0;
-    for (size_t i = 0; i < depth.size(); i++) { covered += depth[i] < 1.0f; lit += hdr[i * 4] != 0; }
-    std::printf("chunks=%u selected=%zu lods=%d range0=%g covered=%zu lit=%zu\n", editorParams.m_NumChunks,
-                quadTree.GetSelectedNodes().size(), quadTree.GetNumLods(), ranges[0], covered, lit);
+    std::vector<uint8_t> ldr;
+    if (!renderTargets.DownloadLdrColor(ldr)) return 2;
+    size_t covered = 0, lit = 0, shown = 0;
+    for (size_t i = 0; i < depth.size(); i++) { covered += depth[i] < 1.0f; lit += hdr[i * 4] != 0; shown += ldr[i * 4 + 1] > 0 && ldr[i * 4 + 3] == 255; }
+    std::printf("chunks=%u selected=%zu lods=%d range0=%g covered=%zu lit=%zu shown=%zu\n", editorParams.m_NumChunks,
+                quadTree.GetSelectedNodes().size(), quadTree.GetNumLods(), ranges[0], covered, lit, shown);
     const bool ok = editorParams.m_NumChunks > 0 && quadTree.GetSelectedNodes().size() == editorParams.m_NumChunks
-                 && ranges[0] == 4.0f && covered > 0 && lit > 0;
+                 && ranges[0] == 4.0f && covered > 0 && lit > 0 && shown > 0;
     return ok ? 0 : 4;
 }

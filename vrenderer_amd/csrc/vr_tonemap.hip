@@ -50,7 +50,9 @@ __device__ __forceinline__ float tm_exp2_pinned(float x)
     return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
 }
 
-// one pixel into the workgroup's LDS histogram
+// One pixel into the workgroup's LDS histogram.  Neighbouring pixels have similar luminance, so a wave's
+// 64 atomics would pile onto one or two addresses: s_hist is the lane's own copy out of kHistCopies.
+constexpr int kHistCopies = 16;
 __device__ __forceinline__ void tm_bin_pixel(uint32_t* __restrict__ s_hist, const TmArgs& a, float r, float g, float b)
 {
     const float lum = tm_luminance(r, g, b);
@@ -132,8 +134,9 @@ template <bool PACKED>
 __global__ __launch_bounds__(256) void k_tm_histogram(TmArgs a, const void* __restrict__ src, const int32_t* __restrict__ owned_tiles,
                                                        size_t num_blocks, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t s_hist[VR_TONEMAP_BINS];
-    s_hist[threadIdx.x] = 0u;
+    __shared__ uint32_t s_all[kHistCopies * VR_TONEMAP_BINS];
+    for (int i = threadIdx.x; i < kHistCopies * VR_TONEMAP_BINS; i += 256) s_all[i] = 0u;
+    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * VR_TONEMAP_BINS;
     __syncthreads();
     for (size_t blk = blockIdx.x; blk < num_blocks; blk += gridDim.x) {
         const QuadPos q = quad_pos<PACKED>(a, owned_tiles, blk, (int)threadIdx.x);
@@ -145,15 +148,18 @@ __global__ __launch_bounds__(256) void k_tm_histogram(TmArgs a, const void* __re
             if (k < q.valid) tm_bin_pixel(s_hist, a, rgb[k][0], rgb[k][1], rgb[k][2]);
     }
     __syncthreads();
-    const uint32_t v = s_hist[threadIdx.x];
+    uint32_t v = 0u;
+#pragma unroll
+    for (int c = 0; c < kHistCopies; c++) v += s_all[c * VR_TONEMAP_BINS + threadIdx.x];
     if (v != 0u) atomicAdd(&hist[threadIdx.x], v);
 }
 
 // any width: one pixel per lane, row-major RGBA16F
 __global__ __launch_bounds__(256) void k_tm_histogram_scalar(TmArgs a, const uint2* __restrict__ src, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t s_hist[VR_TONEMAP_BINS];
-    s_hist[threadIdx.x] = 0u;
+    __shared__ uint32_t s_all[kHistCopies * VR_TONEMAP_BINS];
+    for (int i = threadIdx.x; i < kHistCopies * VR_TONEMAP_BINS; i += 256) s_all[i] = 0u;
+    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * VR_TONEMAP_BINS;
     __syncthreads();
     const size_t n = (size_t)a.w * a.h;
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
@@ -161,30 +167,44 @@ __global__ __launch_bounds__(256) void k_tm_histogram_scalar(TmArgs a, const uin
         tm_bin_pixel(s_hist, a, vr_half_to_float(v.x & 0xffffu), vr_half_to_float(v.x >> 16), vr_half_to_float(v.y & 0xffffu));
     }
     __syncthreads();
-    const uint32_t v = s_hist[threadIdx.x];
+    uint32_t v = 0u;
+#pragma unroll
+    for (int c = 0; c < kHistCopies; c++) v += s_all[c * VR_TONEMAP_BINS + threadIdx.x];
     if (v != 0u) atomicAdd(&hist[threadIdx.x], v);
 }
 
-// ---- ComputeExposure: one lane, the oracle's sequential loop -------------------------------
-__global__ void k_tm_exposure(const uint32_t* __restrict__ hist, float* __restrict__ exposure, float scale, float bias, float low, float high,
-                              float min_log, float min_adapted, float max_adapted, float k_up, float k_down, int has_up, int has_down)
+// ---- ComputeExposure: 256 lanes, one per bin; same arithmetic as the oracle's (exact integer prefix
+// sums, stride-halving float reductions in a fixed order) ---------------------------------------
+__global__ __launch_bounds__(256) void k_tm_exposure(const uint32_t* __restrict__ hist, float* __restrict__ exposure, float scale, float bias,
+                                                      float low, float high, float min_log, float min_adapted, float max_adapted, float k_up,
+                                                      float k_down, int has_up, int has_down)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long total = 0;
-    for (int i = 0; i < VR_TONEMAP_BINS; i++) total += hist[i];
-    const float ftotal = (float)total;
-    const float lo = ftotal * low, hi = ftotal * high;
-    float running = 0.0f, accum = 0.0f, wsum = 0.0f;
-    for (int i = 0; i < VR_TONEMAP_BINS; i++) {
-        const float below = running;
-        running = running + (float)hist[i];
-        const float ca = running < lo ? lo : (running > hi ? hi : running);
-        const float cb = below < lo ? lo : (below > hi ? hi : below);
-        const float wgt = ca - cb;
-        const float log_lum = ((float)i / (float)(VR_TONEMAP_BINS - 1) - bias) / scale;
-        accum = accum + log_lum * wgt;
-        wsum = wsum + wgt;
+    __shared__ unsigned long long pre[VR_TONEMAP_BINS];
+    __shared__ float acc[VR_TONEMAP_BINS], wgt[VR_TONEMAP_BINS];
+    const int i = threadIdx.x;
+    pre[i] = hist[i];
+    __syncthreads();
+    for (int d = 1; d < VR_TONEMAP_BINS; d <<= 1) {          // inclusive scan (integers: any order gives the same sums)
+        const unsigned long long v = i >= d ? pre[i - d] : 0ull;
+        __syncthreads();
+        pre[i] += v;
+        __syncthreads();
     }
+    const float ftotal = (float)pre[VR_TONEMAP_BINS - 1];
+    const float lo = ftotal * low, hi = ftotal * high;
+    const float below = i > 0 ? (float)pre[i - 1] : 0.0f, running = (float)pre[i];
+    const float ca = running < lo ? lo : (running > hi ? hi : running);
+    const float cb = below < lo ? lo : (below > hi ? hi : below);
+    const float w = ca - cb;
+    const float log_lum = ((float)i / (float)(VR_TONEMAP_BINS - 1) - bias) / scale;
+    acc[i] = log_lum * w; wgt[i] = w;
+    __syncthreads();
+    for (int stride = VR_TONEMAP_BINS / 2; stride >= 1; stride >>= 1) {
+        if (i < stride) { acc[i] = acc[i] + acc[i + stride]; wgt[i] = wgt[i] + wgt[i + stride]; }
+        __syncthreads();
+    }
+    if (i != 0) return;
+    const float accum = acc[0], wsum = wgt[0];
     const float avg_log = wsum > 0.0f ? accum / wsum : min_log;
     float target = tm_exp2_pinned(avg_log);
     if (target < min_adapted) target = min_adapted;
@@ -200,14 +220,13 @@ __global__ void k_tm_exposure(const uint32_t* __restrict__ hist, float* __restri
 }
 
 // ---- Render: extended Reinhard on luminance, SRGBA8 out ------------------------------------
-__device__ __forceinline__ uint32_t tm_pixel(const TmArgs& a, float adapted, const float c[3], const float* __restrict__ thr,
+__device__ __forceinline__ uint32_t tm_pixel(const TmArgs& a, float inv_adapted, const float c[3], const float* __restrict__ thr,
                                              const uint8_t* __restrict__ enc)
 {
     const float src = tm_luminance(c[0], c[1], c[2]);
     if (!(src > 0.0f)) return 0u;
-    const float scaled = (a.exposure_scale * src) / adapted;
-    const float mapped = (scaled * (1.0f + scaled * a.wp_inv2)) / (1.0f + scaled);
-    const float k = mapped / src;
+    const float scaled = (a.exposure_scale * src) * inv_adapted;
+    const float k = (scaled * (1.0f + scaled * a.wp_inv2)) / ((1.0f + scaled) * src);     // mapped / src as one division
     return vr_srgb_encode_fast(c[0] * k, thr, enc) | (vr_srgb_encode_fast(c[1] * k, thr, enc) << 8) | (vr_srgb_encode_fast(c[2] * k, thr, enc) << 16);
 }
 
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(256) void k_tonemap(TmArgs a, const void* __restric
     if (q.valid == 0) return;
     float adapted = exposure[0];
     if (!(adapted > 0.0f)) adapted = a.min_adapted;
+    adapted = 1.0f / adapted;                        // used as the reciprocal from here on
     float rgb[4][3];
     load_quad<PACKED>(src, q.index, rgb);
     uint32_t o[4];
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(256) void k_tonemap_scalar(TmArgs a, const uint2* _
     if (p >= (size_t)a.w * a.h) return;
     float adapted = exposure[0];
     if (!(adapted > 0.0f)) adapted = a.min_adapted;
+    adapted = 1.0f / adapted;                        // used as the reciprocal from here on
     const uint2 v = src[p];
     const float c[3] = { vr_half_to_float(v.x & 0xffffu), vr_half_to_float(v.x >> 16), vr_half_to_float(v.y & 0xffffu) };
     dst[p] = tm_pixel(a, adapted, c, thr, enc) | 0xff000000u;
@@ -409,7 +430,7 @@ extern "C" VR_API int vr_tonemap_compute_exposure(vr_tonemap* tm, const vr_tonem
     const float k_up = (float)(1.0 - exp(-(double)frame_time * (double)p->eye_adaptation_speed_up));
     const float k_down = (float)(1.0 - exp(-(double)frame_time * (double)p->eye_adaptation_speed_down));
     VrKernelScope ks(ctx, VR_K_TM_EXPOSURE);
-    hipLaunchKernelGGL(k_tm_exposure, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)tm->d_hist, tm->d_exposure, a.scale, a.bias,
+    hipLaunchKernelGGL(k_tm_exposure, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)tm->d_hist, tm->d_exposure, a.scale, a.bias,
                        p->histogram_low_percentile, p->histogram_high_percentile, p->min_log_luminance, p->min_adapted_luminance,
                        p->max_adapted_luminance, k_up, k_down, p->eye_adaptation_speed_up > 0.0f ? 1 : 0, p->eye_adaptation_speed_down > 0.0f ? 1 : 0);
     VR_HIP(hipGetLastError());
