@@ -260,6 +260,41 @@ VR_API int  vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbu
                                     const float ambient_top[3], const float ambient_bottom[3],
                                     vr_image* hdr_out, const vr_partition* part);
 
+/* ---- terrain shadows ---------------------------------------- */
+/* The reference renders the terrain depth-only from the sun into a 2048^2 one-cascade shadow map every
+ * frame and the deferred pass consumes it (Renderer.cpp:83-93, 333-367, 427).  CascadedShadowMap and the
+ * shadow lookup are Donut code (absent): [DONUT-RECOLLECTION] "stable" cascade = bounding sphere of the
+ * camera frustum slice [0, maxShadowDistance], centre snapped to shadow texels in light space,
+ * orthographic D3D projection; lookup = 4x4 GatherCmp tent PCF (weights [1-f,1,1,f]^2 / 9), LessEqual. */
+typedef struct vr_shadow_params {
+    int32_t resolution;            /* 2048 (Renderer.cpp:83) */
+    float   max_shadow_distance;   /* WORLD_SIZE (:349) */
+    float   light_space_z_up;      /* WORLD_SIZE (:350-352) */
+    float   light_space_z_down;    /* WORLD_SIZE */
+    float   depth_bias;            /* in shadow-map depth units, subtracted from the receiver; 0: the terrain
+                                      depth pass has no raster bias (TerrainPass.cpp:467-471) */
+    int32_t reserved[3];
+} vr_shadow_params;
+VR_API void vr_shadow_default_params(vr_shadow_params* out, float world_size);
+/* CascadedShadowMap::SetupForPlanarViewStable(light, projectionFrustum, inverseViewMatrix, maxShadowDistance,
+ * zUp, zDown, exponent, 0, 1) for the single cascade (Renderer.cpp:345-352): the light's view, to be
+ * rendered with vr_terrain_render(depth_only = 1) into a resolution^2 vr_gbuffer (m_ShadowFramebuffer). */
+VR_API int  vr_shadow_view_setup(const vr_light* light, const vr_view* camera_view, const vr_shadow_params* p,
+                                 vr_view* out_light_view);
+/* what DirectionalLight::shadowMap hands to the lighting pass */
+typedef struct vr_shadow_binding {
+    const vr_view* light_view;
+    vr_gbuffer*    shadow_map;     /* its depth plane is sampled */
+    int32_t        light_index;    /* which entry of `lights` casts it */
+    float          depth_bias;
+} vr_shadow_binding;
+/* vr_deferred_light with the shadow term on one light (vr_light.out_of_bounds_shadow outside the map). */
+VR_API int  vr_deferred_light_shadowed(vr_context* ctx, const vr_view* view, vr_gbuffer* gb,
+                                       const vr_light* lights, int32_t num_lights,
+                                       const float ambient_top[3], const float ambient_bottom[3],
+                                       vr_image* hdr_out, const vr_partition* part,
+                                       const vr_shadow_binding* shadow);
+
 /* ---- multi-GPU frame assembly (new) -------------------------------- */
 VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_partition* part,
                                      int32_t* tiles_x, int32_t* tiles_y, int32_t* owned,

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from vrenderer_amd.capi import (Instance, Light, Partition, RenderParams, TerrainParams, TonemapParams, View, VR_MAX_LODS,
+from vrenderer_amd.capi import (Instance, Light, Partition, RenderParams, ShadowParams, TerrainParams, TonemapParams, View, VR_MAX_LODS,
                                 VR_TONEMAP_BINS)
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +72,8 @@ def lib():
     L.orc_linear_to_srgb8.restype = C.c_uint8
     L.orc_linear_to_srgb8.argtypes = [C.c_float]
     L.orc_linear_to_srgb8_batch.argtypes = [vp, C.c_size_t, vp]
+    L.orc_shadow_view.argtypes = [P(Light), P(View), P(ShadowParams), P(View)]
+    L.orc_deferred_set_shadow.argtypes = [P(View), vp, C.c_int, C.c_int, C.c_float]
     L.orc_tonemap_histogram.argtypes = [P(TonemapParams), vp, C.c_int, C.c_int, P(Partition), vp]
     L.orc_tonemap_exposure.restype = C.c_float
     L.orc_tonemap_exposure.argtypes = [P(TonemapParams), vp, C.c_float, C.c_float]
@@ -214,7 +216,25 @@ class OracleTerrain:
                                 _ptr(gb.normals), _ptr(gb.emissive))
 
 
-def deferred(view, gb, lights, amb_top, amb_bottom, f32=False):
+def shadow_view(light, camera_view, params):
+    v = View()
+    lib().orc_shadow_view(C.byref(light), C.byref(camera_view), C.byref(params), C.byref(v))
+    return v
+
+
+def deferred(view, gb, lights, amb_top, amb_bottom, f32=False, shadow=None):
+    """shadow = (light_view, depth array res x res float32, light_index, depth_bias) or None."""
+    if shadow is not None:
+        lv, sd, li, bias = shadow
+        sd = np.ascontiguousarray(sd, np.float32)
+        lib().orc_deferred_set_shadow(C.byref(lv), _ptr(sd), sd.shape[0], li, bias)
+    try:
+        return _deferred(view, gb, lights, amb_top, amb_bottom, f32)
+    finally:
+        lib().orc_deferred_set_shadow(None, None, 0, 0, 0.0)
+
+
+def _deferred(view, gb, lights, amb_top, amb_bottom, f32=False):
     n = len(lights)
     arr = (Light * max(n, 1))(*lights)
     if f32:

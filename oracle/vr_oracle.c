@@ -578,6 +578,57 @@ void orc_view_from_camera(const float eye[3], const float target[3], const float
     o->reverse_depth = 0;
 }
 
+/* CascadedShadowMap::SetupForPlanarViewStable for the one cascade the reference asks for
+ * (Renderer.cpp:345-352) [DONUT-RECOLLECTION]: bounding sphere of the camera frustum slice
+ * [0, maxShadowDistance]; its centre is snapped to whole shadow-map texels along the light's x / y axes so
+ * that the map does not shimmer when the camera moves ("stable"); orthographic D3D-style projection over
+ * [-radius, radius]^2 x [centre - zUp, centre + zDown] along the light direction. */
+void orc_shadow_view(const vr_light* light, const vr_view* cam, const vr_shadow_params* p, vr_view* o)
+{
+    memset(o, 0, sizeof(*o));
+    const float* W = cam->world_to_view;
+    float fwd[3] = { W[2], W[6], W[10] };                       /* view +z in world space */
+    float d = p->max_shadow_distance;
+    float hw = d / cam->view_to_clip[0], hh = d / cam->view_to_clip[5];
+    float r2 = hw * hw + hh * hh;                               /* far-plane half diagonal, squared */
+    float c = (d * d + r2) / (2.0f * d);                        /* sphere through the apex and the far corners */
+    if (c > d) c = d;
+    float radius = sqrtf((d - c) * (d - c) + r2);
+    float centre[3] = { cam->camera_pos[0] + fwd[0] * c, cam->camera_pos[1] + fwd[1] * c, cam->camera_pos[2] + fwd[2] * c };
+    float zl[3] = { light->direction[0], light->direction[1], light->direction[2] };
+    normalize3(zl);
+    float up[3] = { 0.0f, 1.0f, 0.0f };
+    if (fabsf(zl[1]) > 0.99f) { up[1] = 0.0f; up[2] = 1.0f; }
+    float xl[3], yl[3];
+    cross3(up, zl, xl); normalize3(xl);
+    cross3(zl, xl, yl);
+    float texel = (2.0f * radius) / (float)p->resolution;
+    float cx = floorf(dot3(centre, xl) / texel) * texel, cy = floorf(dot3(centre, yl) / texel) * texel;
+    float cz = dot3(centre, zl) - p->light_space_z_up;          /* near plane */
+    float origin[3];
+    for (int k = 0; k < 3; k++) origin[k] = (xl[k] * cx + yl[k] * cy) + zl[k] * cz;
+    float* m = o->world_to_view;
+    for (int i = 0; i < 3; i++) { m[i*4+0] = xl[i]; m[i*4+1] = yl[i]; m[i*4+2] = zl[i]; m[i*4+3] = 0.0f; }
+    float no[3] = { -origin[0], -origin[1], -origin[2] };
+    m[12] = dot3(no, xl); m[13] = dot3(no, yl); m[14] = dot3(no, zl); m[15] = 1.0f;
+    float* q = o->view_to_clip;                                  /* orthoProjD3DStyle */
+    q[0] = 1.0f / radius; q[5] = 1.0f / radius; q[10] = 1.0f / (p->light_space_z_up + p->light_space_z_down); q[15] = 1.0f;
+    mat4_mul(o->world_to_view, o->view_to_clip, o->world_to_clip);
+    mat4_inverse_d(o->world_to_clip, o->clip_to_world);
+    o->camera_pos[0] = origin[0]; o->camera_pos[1] = origin[1]; o->camera_pos[2] = origin[2]; o->camera_pos[3] = 1.0f;
+    const float* cc = o->world_to_clip;
+    set_plane(o->planes[0], -cc[2],          -cc[6],          -cc[10],           cc[14]);
+    set_plane(o->planes[1], -cc[3] + cc[2],  -cc[7] + cc[6],  -cc[11] + cc[10],  cc[15] - cc[14]);
+    set_plane(o->planes[2], -cc[3] - cc[0],  -cc[7] - cc[4],  -cc[11] - cc[8],   cc[15] + cc[12]);
+    set_plane(o->planes[3], -cc[3] + cc[0],  -cc[7] + cc[4],  -cc[11] + cc[8],   cc[15] - cc[12]);
+    set_plane(o->planes[4], -cc[3] + cc[1],  -cc[7] + cc[5],  -cc[11] + cc[9],   cc[15] - cc[13]);
+    set_plane(o->planes[5], -cc[3] - cc[1],  -cc[7] - cc[5],  -cc[11] - cc[9],   cc[15] + cc[13]);
+    o->viewport_x = 0; o->viewport_y = 0; o->viewport_w = p->resolution; o->viewport_h = p->resolution;
+    float det = xl[0] * (yl[1]*zl[2] - yl[2]*zl[1]) - yl[0] * (xl[1]*zl[2] - xl[2]*zl[1]) + zl[0] * (xl[1]*yl[2] - xl[2]*yl[1]);
+    o->mirrored = det < 0.0f;
+    o->reverse_depth = 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* vertex stage: main_vs (terrain_vs.hlsl:10-62)                               */
 /* ------------------------------------------------------------------------- */
@@ -969,7 +1020,7 @@ int orc_render(orc_terrain* t, const vr_view* v, const vr_render_params* rp, con
 /* deferred lighting [DONUT-RECOLLECTION of render::DeferredLightingPass,     */
 /* deferred_lighting_cs.hlsl, lighting.hlsli ShadeSurface, brdf.hlsli          */
 /* GGX_AnalyticalLights_times_NdotL]; inputs per Renderer.cpp:417-428.         */
-/* Shadows are row f1 (next): shadow factor = 1.                               */
+/* Shadow term (row f1): 4x4 tent PCF on the terrain shadow map, see shadow_factor. */
 /* The area-light correction slerp(L, R, saturate(halfAngle/angle(L,R))) is     */
 /* restated in closed form (no acos/sin per pixel):                            */
 /*   angle <= half  -> R;  else  L*(cosH - cosT*sinH/sinT) + R*(sinH/sinT).     */
@@ -979,10 +1030,43 @@ int orc_render(orc_terrain* t, const vr_view* v, const vr_render_params* rp, con
 
 typedef struct { float cosH, sinH, tanH; } orc_light_consts;
 
+/* What DirectionalLight::shadowMap gives the lighting pass (Renderer.cpp:336, 427) [DONUT-RECOLLECTION of
+ * EvaluateShadowGather16]: world -> light clip -> uv; outside the map: outOfBoundsShadow; else the 4x4 texel
+ * footprint around the sample, each texel compared LessEqual (receiver depth - bias <= stored depth),
+ * weighted [1-fx, 1, 1, fx] x [1-fy, 1, 1, fy], normalised by 9. */
+typedef struct { const vr_view* light_view; const float* depth; int res; int light_index; float depth_bias; } orc_shadow;
+
+static float shadow_factor(const orc_shadow* s, const float wp[3], float out_of_bounds)
+{
+    float p4[4] = { wp[0], wp[1], wp[2], 1.0f }, c[4];
+    mul_row4(p4, s->light_view->world_to_clip, c);
+    float xc = c[0] / c[3], yc = c[1] / c[3], zc = c[2] / c[3];
+    float u = xc * 0.5f + 0.5f, v = 0.5f - yc * 0.5f;
+    if (!(u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f && zc >= 0.0f && zc <= 1.0f)) return out_of_bounds;
+    float z = zc - s->depth_bias;
+    float tx = u * (float)s->res - 0.5f, ty = v * (float)s->res - 0.5f;
+    float fxl = floorf(tx), fyl = floorf(ty);
+    float fx = tx - fxl, fy = ty - fyl;
+    int ix = (int)fxl - 1, iy = (int)fyl - 1;
+    float wx[4] = { 1.0f - fx, 1.0f, 1.0f, fx }, wy[4] = { 1.0f - fy, 1.0f, 1.0f, fy };
+    float sum = 0.0f;
+    for (int j = 0; j < 4; j++) {
+        int y = iy + j; y = y < 0 ? 0 : (y > s->res - 1 ? s->res - 1 : y);
+        float row = 0.0f;
+        for (int i = 0; i < 4; i++) {
+            int x = ix + i; x = x < 0 ? 0 : (x > s->res - 1 ? s->res - 1 : x);
+            float lit = z <= s->depth[(size_t)y * s->res + x] ? 1.0f : 0.0f;
+            row = row + lit * wx[i];
+        }
+        sum = sum + row * wy[j];
+    }
+    return sum / 9.0f;
+}
+
 static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
                         float depth, uint32_t diff, uint32_t spec, const uint16_t nrm[4], const uint16_t emi[4],
                         const vr_light* lights, const orc_light_consts* lc, int nl,
-                        const float amb_top[3], const float amb_bot[3], float out[4])
+                        const float amb_top[3], const float amb_bot[3], const orc_shadow* shadow, float out[4])
 {
     float albedo[3] = { g_srgb_lut[diff & 255u], g_srgb_lut[(diff >> 8) & 255u], g_srgb_lut[(diff >> 16) & 255u] };
     float F0[3] = { g_srgb_lut[spec & 255u], g_srgb_lut[(spec >> 8) & 255u], g_srgb_lut[(spec >> 16) & 255u] };
@@ -1048,6 +1132,11 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
             }
             irr = irr * (spotlight * att);
         }
+        if (shadow && i == shadow->light_index) {
+            float sf = shadow_factor(shadow, wp, L_->out_of_bounds_shadow);
+            if (sf == 0.0f) continue;
+            irr = irr * sf;
+        }
         float L[3] = { -Lin[0], -Lin[1], -Lin[2] };
         /* diffuse: Lambert */
         float NdotLd = fmaxx(dot3(N, L), 0.0f);
@@ -1092,6 +1181,17 @@ static void shade_pixel(const vr_view* v, int w, int h, int px, int py,
     out[3] = 0.0f;
 }
 
+/* optional shadow binding of the next orc_deferred* call (set by orc_deferred_set_shadow, test harness is single-threaded) */
+static const orc_shadow* g_shadow = NULL;
+static orc_shadow g_shadow_store;
+void orc_deferred_set_shadow(const vr_view* light_view, const float* shadow_depth, int res, int light_index, float depth_bias)
+{
+    if (!light_view || !shadow_depth) { g_shadow = NULL; return; }
+    g_shadow_store.light_view = light_view; g_shadow_store.depth = shadow_depth; g_shadow_store.res = res;
+    g_shadow_store.light_index = light_index; g_shadow_store.depth_bias = depth_bias;
+    g_shadow = &g_shadow_store;
+}
+
 static orc_light_consts* light_consts(const vr_light* lights, int n)
 {
     orc_light_consts* lc = (orc_light_consts*)malloc(sizeof(orc_light_consts) * (n > 0 ? n : 1));
@@ -1110,7 +1210,7 @@ void orc_deferred_f32(const vr_view* v, int w, int h, const float* depth, const 
     orc_light_consts* lc = light_consts(lights, nl);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
         size_t i = (size_t)y * w + x;
-        shade_pixel(v, w, h, x, y, depth[i], diffuse[i], specular[i], &normals[i*4], &emissive[i*4], lights, lc, nl, amb_top, amb_bottom, &rgba[i*4]);
+        shade_pixel(v, w, h, x, y, depth[i], diffuse[i], specular[i], &normals[i*4], &emissive[i*4], lights, lc, nl, amb_top, amb_bottom, g_shadow, &rgba[i*4]);
     }
     free(lc);
 }
@@ -1123,7 +1223,7 @@ void orc_deferred(const vr_view* v, int w, int h, const float* depth, const uint
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
         size_t i = (size_t)y * w + x;
         float o[4];
-        shade_pixel(v, w, h, x, y, depth[i], diffuse[i], specular[i], &normals[i*4], &emissive[i*4], lights, lc, nl, amb_top, amb_bottom, o);
+        shade_pixel(v, w, h, x, y, depth[i], diffuse[i], specular[i], &normals[i*4], &emissive[i*4], lights, lc, nl, amb_top, amb_bottom, g_shadow, o);
         for (int c = 0; c < 4; c++) hdr[i*4+c] = orc_float_to_half(o[c]);
     }
     free(lc);

@@ -56,6 +56,13 @@ void   orc_node_heights(const orc_terrain* t, float* out, long max_ids);   /* (p
 void   orc_view_from_camera(const float eye[3], const float target[3], const float up[3],
                             float vfov, float z_near, float z_far, int w, int h, vr_view* out);
 
+/* CascadedShadowMap::SetupForPlanarViewStable, one cascade (Renderer.cpp:345-352) [DONUT-RECOLLECTION]. */
+void   orc_shadow_view(const vr_light* light, const vr_view* camera_view, const vr_shadow_params* p, vr_view* out);
+/* Shadow binding used by the following orc_deferred / orc_deferred_f32 calls (NULL view or depth = none):
+ * the light `light_index` is multiplied by the 4x4 tent-PCF lookup into the res^2 depth map. */
+void   orc_deferred_set_shadow(const vr_view* light_view, const float* shadow_depth, int res, int light_index,
+                               float depth_bias);
+
 /* main_vs for one vertex of one instance (terrain_vs.hlsl:35-62). */
 void   orc_vertex(const orc_terrain* t, const vr_view* v, float max_height,
                   const vr_instance* inst, int vx, int vz, float clip[4], float world[3]);

@@ -786,3 +786,83 @@ def test_tonemap_on_packed_tiles_and_ldr_detile(scene256, oracle, gpu_ctx, world
     assert mis.size == 0, f"assembled LDR frame differs at {len(mis)} bytes, first {mis[:4].tolist()}"
     for b in packed: b.close()
     g_dev.close(); frame.close(); tm.close(); full.close()
+
+
+def _shadow_setup(sc, oracle, gpu_ctx, cam_index, w, h, res, bias):
+    size = sc["size"]
+    eye, tgt = scaled_camera(CAMERAS[cam_index], size)
+    cam = vr.make_view(eye, tgt, w, h)
+    sun = vr.reference_sun()
+    sm = vr.CascadedShadowMap(gpu_ctx, vr.default_shadow_params(float(size), resolution=res, depth_bias=bias))
+    lv = sm.SetupForPlanarViewStable(sun, cam)
+    sm.Clear()
+    sm.RenderTerrain(sc["tp"])                                  # "Terrain Shadow" (Renderer.cpp:356-372)
+    # the same pass through the oracle
+    gb_l = oracle.GBufferHost(res, res)
+    sc["ot"].render(lv, gb_l, vr.default_render_params(400.0, depth_only=1))
+    return cam, sun, sm, lv, gb_l
+
+
+def test_terrain_shadow_pass_depth_bit_exact(scene256, oracle, gpu_ctx):
+    """TerrainPass::Render(depthOnly) from the cascade's orthographic light view (Renderer.cpp:356-372)."""
+    cam, sun, sm, lv, gb_l = _shadow_setup(scene256, oracle, gpu_ctx, 0, 640, 360, 512, 0.0)
+    got = sm.download_depth()
+    mis = np.argwhere(got.view(np.uint32) != gb_l.depth.view(np.uint32))
+    assert mis.size == 0, f"shadow depth differs at {len(mis)} texels, first {mis[:4].tolist()}"
+    assert (got < 1.0).mean() > 0.001 and scene256["tp"].num_chunks() > 0
+    sm.close()
+
+
+@pytest.mark.parametrize("cam_index,bias", [(0, 0.0), (5, 0.002), (7, 0.002)])
+def test_shadowed_deferred_rms(scene256, oracle, gpu_ctx, cam_index, bias):
+    """DeferredLightingPass with DirectionalLight::shadowMap set (Renderer.cpp:336, 427): per-channel RMS <= 1e-4
+    vs the oracle, and no pixel flips its PCF comparisons (max error stays at rounding level)."""
+    w, h, res = 640, 360, 512
+    cam, sun, sm, lv, gb_l = _shadow_setup(scene256, oracle, gpu_ctx, cam_index, w, h, res, bias)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    scene256["tp"].Render(cam, cam, rt, vr.default_render_params(400.0, assume_cleared=1))
+    hdr, hdr_plain = vr.HdrImage(gpu_ctx, w, h), vr.HdrImage(gpu_ctx, w, h)
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    dl.Render(cam, rt, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, hdr, shadow_map=sm)
+    dl.Render(cam, rt, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, hdr_plain)
+    gb = oracle.GBufferHost(w, h)
+    for name, arr in (("depth", gb.depth), ("diffuse", gb.diffuse), ("specular", gb.specular), ("normals", gb.normals), ("emissive", gb.emissive)):
+        arr[...] = rt.download(name)
+    want = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv, gb_l.depth, 0, bias))
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    plain = oracle.half_to_float(hdr_plain.download()).astype(np.float64)
+    err = got[..., :3] - want[..., :3].astype(np.float64)
+    rms = np.sqrt((err ** 2).mean(axis=(0, 1)))
+    assert (rms <= 1e-4).all(), rms
+    assert np.abs(err).max() < 2e-3, np.abs(err).max()          # half rounding of values < 1; a flipped comparison would be ~0.1
+    shadowed = (plain[..., 1] - got[..., 1]) > 1e-3
+    assert shadowed.mean() > 0.01, "the frame has no shadowed pixels: the test would not exercise the lookup"
+    assert (got <= plain + 1e-3).all()
+    for o in (hdr, hdr_plain, rt, sm): o.close()
+
+
+def test_shadowed_deferred_on_packed_tiles(scene256, oracle, gpu_ctx):
+    w, h, res, world = 640, 360, 512, 2
+    cam, sun, sm, lv, _ = _shadow_setup(scene256, oracle, gpu_ctx, 5, w, h, res, 0.002)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    scene256["tp"].Render(cam, cam, rt, vr.default_render_params(400.0, assume_cleared=1))
+    full = vr.HdrImage(gpu_ctx, w, h)
+    dl.Render(cam, rt, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, full, shadow_map=sm)
+    ref = full.download()
+    from vrenderer_amd import partition as pt
+    from vrenderer_amd.passes import partition_info
+    info = partition_info(w, h, 0, world)
+    rows = (info["packed_bytes"] + 8 * 128 - 1) // (8 * 128)
+    for r in range(world):
+        part = vr.Partition(r, world)
+        buf = vr.HdrImage(gpu_ctx, 128, rows)
+        dl.Render(cam, rt, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, buf, part, shadow_map=sm)
+        packed = buf.download(info["packed_bytes"]).reshape(-1, 128, 128, 3)
+        tx, _ = pt.owner_grid(w, h)
+        for lt, tile in enumerate(pt.owned_tiles(w, h, r, world)):
+            y0, x0 = (tile // tx) * 128, (tile % tx) * 128
+            hh, ww = min(128, h - y0), min(128, w - x0)
+            assert np.array_equal(packed[lt, :hh, :ww], ref[y0:y0 + hh, x0:x0 + ww, :3]), (r, tile)
+        buf.close()
+    for o in (full, rt, sm): o.close()

@@ -411,3 +411,79 @@ def test_tonemap_known_answers(oracle):
     img = np.zeros((1, 2, 4), np.float16); img[0, 1, :3] = np.inf
     out = oracle.ToneMapper().SimpleRender(p, img.view(np.uint16))
     assert out[0, 0].tolist() == [0, 0, 0, 255] and out[0, 1, 3] == 255
+
+
+def test_shadow_view_and_shadow_term_known_answers(oracle, t256):
+    """Row f1: the one-cascade "stable" light view (Renderer.cpp:345-352) and the PCF shadow term."""
+    import ctypes as C
+    lib = vr.load_library()
+    sun = vr.reference_sun()
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    cam = oracle.view_from_camera(eye, tgt, 480, 270)
+    p = vr.default_shadow_params(256.0, resolution=256)
+    lv = oracle.shadow_view(sun, cam, p)
+    host = vr.View()
+    assert lib.vr_shadow_view_setup(C.byref(sun), C.byref(cam), C.byref(p), C.byref(host)) == 0
+    for f in ("world_to_view", "view_to_clip", "world_to_clip", "clip_to_world", "camera_pos"):
+        assert np.array_equal(np.array(getattr(host, f)[:]), np.array(getattr(lv, f)[:])), f      # library host code == restatement
+    w2v = np.array(lv.world_to_view[:], np.float64).reshape(4, 4)
+    d = np.array(sun.direction[:], np.float64)
+    assert np.allclose(w2v[:3, 2], d / np.linalg.norm(d), atol=1e-6)                 # looks along the light
+    assert np.allclose(w2v[:3, :3].T @ w2v[:3, :3], np.eye(3), atol=1e-5) and lv.mirrored == 0
+    radius = 1.0 / lv.view_to_clip[0]
+    # in x and y the box holds the camera and the four corners of the frustum slice at maxShadowDistance
+    c2w = np.array(cam.clip_to_world[:], np.float64).reshape(4, 4)
+    w2c_l = np.array(lv.world_to_clip[:], np.float64).reshape(4, 4)
+    fwd = np.array(cam.world_to_view[:], np.float64).reshape(4, 4)[:3, 2]
+    pts = [np.array(cam.camera_pos[:3], np.float64)]
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            q = np.array([sx, sy, 1.0, 1.0]) @ c2w
+            far = q[:3] / q[3]
+            ray = far - pts[0]
+            pts.append(pts[0] + ray * (256.0 / (ray @ fwd)))
+    texel = 2.0 * radius / 256
+    for q in pts:
+        ndc = np.append(q, 1.0) @ w2c_l
+        assert abs(ndc[0]) <= 1.0 + 2 * texel / radius and abs(ndc[1]) <= 1.0 + 2 * texel / radius      # z: the caller's zUp / zDown, not the sphere
+    # stable: the light-space origin sits on the texel grid, so a small camera move shifts it by whole texels
+    cam2 = oracle.view_from_camera((eye[0] + 0.37, eye[1], eye[2] - 0.21), tgt, 480, 270)
+    lv2 = oracle.shadow_view(sun, cam2, p)
+    shift = (np.array(lv2.camera_pos[:3], np.float64) - np.array(lv.camera_pos[:3], np.float64)) @ w2v[:3, :2] / texel
+    assert np.allclose(shift, np.round(shift), atol=2e-3)
+
+    # shadow term on a lit frame
+    gb = oracle.GBufferHost(480, 270)
+    t256.render(cam, gb, vr.default_render_params(400.0))
+    plain = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    none = oracle.deferred(cam, gb, [], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    covered = gb.depth < 1.0
+    open_map = np.ones((256, 256), np.float32)                                   # nothing between the light and anything
+    lit = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv, open_map, 0, 0.0))
+    assert np.array_equal(lit, plain)
+    blocked = np.zeros((256, 256), np.float32)                                   # an occluder at depth 0 everywhere
+    dark = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv, blocked, 0, 0.0))
+    assert np.array_equal(dark[covered], none[covered])                          # only the ambient term is left
+    # block the map's columns left of the middle of what the camera sees: dark side, lit side, and a PCF ramp between
+    ys, xs = np.nonzero(covered)
+    clip = np.stack([(xs + 0.5) * 2 / 480 - 1, 1 - (ys + 0.5) * 2 / 270, gb.depth[ys, xs].astype(np.float64), np.ones(len(xs))], 1)
+    wpos = clip @ c2w
+    u_tex = ((wpos / wpos[:, 3:4]) @ w2c_l)[:, 0] * 0.5 + 0.5
+    split = int(np.median(u_tex) * 256)
+    half = np.ones((256, 256), np.float32); half[:, :split] = 0.0
+    mixed = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv, half, 0, 0.0))
+    sunlit = covered & np.any(plain != none, axis=-1)                            # pixels the sun reaches at all
+    is_dark = np.all(mixed == none, axis=-1) & sunlit
+    is_lit = np.all(mixed == plain, axis=-1) & sunlit
+    partial = sunlit & ~is_dark & ~is_lit
+    assert is_dark.sum() > 100 and is_lit.sum() > 100 and 0 < partial.sum() < 0.5 * sunlit.sum()
+    assert (mixed[partial] <= plain[partial] + 1e-7).all() and (mixed[partial] >= none[partial] - 1e-7).all()
+    u_img = np.zeros(covered.shape); u_img[ys, xs] = u_tex * 256
+    assert u_img[is_dark].max() < split + 1.5 and u_img[is_lit].min() > split - 2.5     # the ramp is the 4-texel footprint
+    # outside the map the light's outOfBoundsShadow applies
+    tiny = vr.default_shadow_params(256.0, resolution=256, max_shadow_distance=1.0)
+    lv_t = oracle.shadow_view(sun, cam, tiny)
+    sun_oob = vr.reference_sun(); sun_oob.out_of_bounds_shadow = 1.0
+    out = oracle.deferred(cam, gb, [sun_oob], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv_t, blocked, 0, 0.0))
+    far_px = gb.depth > np.quantile(gb.depth[covered], 0.5)
+    assert np.array_equal(out[far_px & covered], plain[far_px & covered])

@@ -101,6 +101,15 @@ class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world_size", C.c_int32)]
 
 
+class ShadowParams(C.Structure):
+    _fields_ = [("resolution", C.c_int32), ("max_shadow_distance", C.c_float), ("light_space_z_up", C.c_float),
+                ("light_space_z_down", C.c_float), ("depth_bias", C.c_float), ("reserved", C.c_int32 * 3)]
+
+
+class ShadowBinding(C.Structure):
+    _fields_ = [("light_view", C.c_void_p), ("shadow_map", C.c_void_p), ("light_index", C.c_int32), ("depth_bias", C.c_float)]
+
+
 class TonemapParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "histogram_low_percentile", "histogram_high_percentile", "eye_adaptation_speed_up", "eye_adaptation_speed_down",
@@ -124,6 +133,7 @@ EXPORTS = [
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile",
+    "vr_shadow_default_params", "vr_shadow_view_setup", "vr_deferred_light_shadowed",
     "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
     "vr_tonemap_add_frame_to_histogram", "vr_tonemap_histogram_device_ptr", "vr_tonemap_compute_exposure", "vr_tonemap_render",
     "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_render_stats",
@@ -200,6 +210,10 @@ def load_library():
         "vr_partition_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
         "vr_partition_prepare": (C.c_int, [vp, C.c_int32, C.c_int32, P(Partition)]),
         "vr_frame_detile": (C.c_int, [vp, vp, C.c_int32, vp]),
+        "vr_shadow_default_params": (None, [P(ShadowParams), C.c_float]),
+        "vr_shadow_view_setup": (C.c_int, [P(Light), P(View), P(ShadowParams), P(View)]),
+        "vr_deferred_light_shadowed": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
+                                                 vp, P(Partition), P(ShadowBinding)]),
         "vr_tonemap_default_params": (None, [P(TonemapParams)]),
         "vr_tonemap_create": (C.c_int, [vp, P(vp)]),
         "vr_tonemap_destroy": (None, [vp]),

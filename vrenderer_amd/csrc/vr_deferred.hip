@@ -177,18 +177,77 @@ __device__ __forceinline__ void finish_pixel(const DeferredArgs& a, const Surfac
     }
 }
 
+// ---- shadow term (row f1) -----------------------------------------------------------------------
+// [DONUT-RECOLLECTION of EvaluateShadowGather16] world -> light clip -> uv; outside the map:
+// outOfBoundsShadow; else the 4x4 texel footprint, each texel compared LessEqual (receiver depth - bias
+// <= stored depth), weights [1-fx, 1, 1, fx] x [1-fy, 1, 1, fy] / 9.  A comparison is a step function,
+// so unlike the BRDF this part is evaluated exactly as the checker does: IEEE divisions, no contraction,
+// its own world-position reconstruction (the shaded one uses v_rcp_f32) - otherwise pixels whose receiver
+// depth sits on a stored depth would flip and the RMS contract could not hold.
+struct ShadowArgs {
+    float w2c[16];                 // light's world -> clip
+    const float* depth;            // res x res shadow map
+    int res, light_index;
+    float bias, out_of_bounds;
+};
+
+__device__ __forceinline__ float shadow_factor(const DeferredArgs& a, const ShadowArgs& s, int px, int py, float depth)
+{
+    const float cx = ((float)px + 0.5f) * a.sx + -1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+    float w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
+    const float wx_ = w4[0] / w4[3], wy_ = w4[1] / w4[3], wz_ = w4[2] / w4[3];
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = ((wx_ * s.w2c[0 * 4 + j] + wy_ * s.w2c[1 * 4 + j]) + wz_ * s.w2c[2 * 4 + j]) + s.w2c[3 * 4 + j];
+    const bool w_one = c[3] == 1.0f;                                 // orthographic light: x / 1 == x, skip the divisions
+    const float xc = w_one ? c[0] : c[0] / c[3], yc = w_one ? c[1] : c[1] / c[3], zc = w_one ? c[2] : c[2] / c[3];
+    const float u = xc * 0.5f + 0.5f, v = 0.5f - yc * 0.5f;
+    if (!(u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f && zc >= 0.0f && zc <= 1.0f)) return s.out_of_bounds;
+    const float z = zc - s.bias;
+    const float tx = u * (float)s.res - 0.5f, ty = v * (float)s.res - 0.5f;
+    const float fxl = floorf(tx), fyl = floorf(ty);
+    const float fx = tx - fxl, fy = ty - fyl;
+    const int ix = (int)fxl - 1, iy = (int)fyl - 1;
+    const float wgx[4] = { 1.0f - fx, 1.0f, 1.0f, fx }, wgy[4] = { 1.0f - fy, 1.0f, 1.0f, fy };
+    int xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xs[i] = min(max(ix + i, 0), s.res - 1);
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float* row_p = s.depth + (size_t)min(max(iy + j, 0), s.res - 1) * s.res;
+        const float d0 = row_p[xs[0]], d1 = row_p[xs[1]], d2 = row_p[xs[2]], d3 = row_p[xs[3]];
+        float row = 0.0f;
+        row = row + (z <= d0 ? 1.0f : 0.0f) * wgx[0];
+        row = row + (z <= d1 ? 1.0f : 0.0f) * wgx[1];
+        row = row + (z <= d2 ? 1.0f : 0.0f) * wgx[2];
+        row = row + (z <= d3 ? 1.0f : 0.0f) * wgx[3];
+        sum = sum + row * wgy[j];
+    }
+    return sum / 9.0f;
+}
+
 // EXTRA: the light list contains spot or spherical lights (compiled out of the common variant, which
 // keeps the streaming kernel at its leanest for directional / punctual lights).
-template <bool EXTRA>
+template <bool EXTRA, bool SHADOW = false>
 __device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
                                             uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
-                                            float out[3])
+                                            float out[3], const ShadowArgs* sh = nullptr)
 {
     const Surface s = decode_surface(a, lut, px, py, depth, diff, spec, n01, n23, e01, e23);
     float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
+    float sf = 1.0f;
+    if (SHADOW) sf = shadow_factor(a, *sh, px, py, depth);
     for (int i = 0; i < a.num_lights; i++) {
         const DevLight& Lc = a.lights[i];
         const float* vec = Lc.type == VR_LIGHT_DIRECTIONAL ? Lc.dir : Lc.pos;
+        if (SHADOW && i == sh->light_index) {          // a directional light (checked on the host): irradiance = intensity * shadow
+            if (sf == 0.0f) continue;
+            add_light(s, Lc.type, vec, Lc.inv_range, Lc.color, Lc.intensity * sf, Lc.cosH, Lc.sinH, Lc.tanH, diffuseTerm, specularTerm);
+            continue;
+        }
         if (EXTRA && (Lc.type == VR_LIGHT_SPOT || Lc.radius > 0.0f)) {
             LightExtra ex; ex.axis[0] = Lc.dir[0]; ex.axis[1] = Lc.dir[1]; ex.axis[2] = Lc.dir[2];
             ex.radius = Lc.radius; ex.inner_angle = Lc.inner_angle; ex.outer_angle = Lc.outer_angle;
@@ -221,12 +280,12 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
 // PACKED = false: whole frame, row-major output; one lane = 4 consecutive pixels.
 // PACKED = true : only owner tiles of this rank, output packed tile-major
 //                 [local tile][128 rows][128 px]; block = 8 rows x 128 px of a tile.
-template <bool PACKED, bool EXTRA>
+template <bool PACKED, bool EXTRA, bool SHADOW = false>
 __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                    const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
                                                    uint2* __restrict__ out, const float* __restrict__ lut_g,
-                                                   const int32_t* __restrict__ owned_tiles)
+                                                   const int32_t* __restrict__ owned_tiles, ShadowArgs sh)
 {
     __shared__ float lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -269,7 +328,7 @@ __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* _
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float rgb[3];
-        shade_pixel<EXTRA>(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb);
+        shade_pixel<EXTRA, SHADOW>(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb, &sh);
         o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
         o[2 * k + 1] = vr_float_to_half(rgb[2]);          // alpha = 0
     }
@@ -280,7 +339,8 @@ __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* _
 __global__ __launch_bounds__(256) void k_deferred_scalar(DeferredArgs a, const float* __restrict__ g_depth,
                                                           const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                           const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
-                                                          uint2* __restrict__ out, const float* __restrict__ lut_g)
+                                                          uint2* __restrict__ out, const float* __restrict__ lut_g, ShadowArgs sh,
+                                                          int use_shadow)
 {
     __shared__ float lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -290,7 +350,8 @@ __global__ __launch_bounds__(256) void k_deferred_scalar(DeferredArgs a, const f
     const int py = (int)(p / (size_t)a.w), px = (int)(p - (size_t)py * a.w);
     const uint2 n = g_nrm[p], e = g_emi[p];
     float rgb[3];
-    shade_pixel<true>(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb);
+    if (use_shadow) shade_pixel<true, true>(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb, &sh);
+    else shade_pixel<true>(a, lut, px, py, g_depth[p], g_diff[p], g_spec[p], n.x, n.y, e.x, e.y, rgb);
     out[p] = make_uint2(vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16), vr_float_to_half(rgb[2]));
 }
 
@@ -310,11 +371,24 @@ static int fill_light(const vr_light& l, DevLight& d, bool allow_extra)
     return VR_OK;
 }
 
-extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
-                                         int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
-                                         vr_image* hdr, const vr_partition* part)
+static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
+                          int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
+                          vr_image* hdr, const vr_partition* part, const vr_shadow_binding* shadow)
 {
     VR_REQUIRE(ctx && view && gb && hdr && amb_top && amb_bottom, "NULL argument");
+    ShadowArgs sh;
+    memset(&sh, 0, sizeof(sh));
+    if (shadow) {
+        VR_REQUIRE(shadow->light_view && shadow->shadow_map, "shadow binding has NULL members");
+        VR_REQUIRE(shadow->light_index >= 0 && shadow->light_index < num_lights, "shadow light_index out of range");
+        VR_REQUIRE(lights[shadow->light_index].type == VR_LIGHT_DIRECTIONAL, "only a directional light carries the cascaded shadow map");
+        VR_REQUIRE(shadow->shadow_map->w == shadow->shadow_map->h && shadow->shadow_map->w == shadow->light_view->viewport_w
+                   && shadow->light_view->viewport_h == shadow->light_view->viewport_w, "shadow map must be square and match the light view's viewport");
+        VR_REQUIRE(shadow->shadow_map->ctx->device == ctx->device, "shadow map lives on another device");
+        for (int i = 0; i < 16; i++) sh.w2c[i] = shadow->light_view->world_to_clip[i];
+        sh.depth = shadow->shadow_map->depth; sh.res = shadow->shadow_map->w; sh.light_index = shadow->light_index;
+        sh.bias = shadow->depth_bias; sh.out_of_bounds = lights[shadow->light_index].out_of_bounds_shadow;
+    }
     VR_REQUIRE(num_lights >= 0 && num_lights <= kMaxLights, "at most 16 lights (terrain_cb.h:15)");
     VR_REQUIRE(num_lights == 0 || lights, "lights is NULL");
     VR_REQUIRE(view->viewport_w == gb->w && view->viewport_h == gb->h && view->viewport_x == 0 && view->viewport_y == 0,
@@ -342,24 +416,40 @@ extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr
         VR_REQUIRE(gb->w % 4 == 0, "partitioned frames need a width that is a multiple of 4");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (ctx->num_owned > 0) {
-            auto kern = extra ? k_deferred<true, true> : k_deferred<true, false>;
+            auto kern = shadow ? k_deferred<true, true, true> : (extra ? k_deferred<true, true> : k_deferred<true, false>);
             hipLaunchKernelGGL(kern, dim3((unsigned)ctx->num_owned * 16), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles);
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles, sh);
         }
     } else {
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         if (gb->w % 4 == 0) {
             const size_t quads = npx / 4;
-            auto kern = extra ? k_deferred<false, true> : k_deferred<false, false>;
+            auto kern = shadow ? k_deferred<false, true, true> : (extra ? k_deferred<false, true> : k_deferred<false, false>);
             hipLaunchKernelGGL(kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr);
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh);
         } else {
             hipLaunchKernelGGL(k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut);
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, sh, shadow ? 1 : 0);
         }
     }
     VR_HIP(hipGetLastError());
     return VR_OK;
+}
+
+extern "C" VR_API int vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
+                                         int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
+                                         vr_image* hdr, const vr_partition* part)
+{
+    return deferred_light(ctx, view, gb, lights, num_lights, amb_top, amb_bottom, hdr, part, nullptr);
+}
+
+// DeferredLightingPass::Render with DirectionalLight::shadowMap set (Renderer.cpp:336, 427)
+extern "C" VR_API int vr_deferred_light_shadowed(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
+                                                  int32_t num_lights, const float amb_top[3], const float amb_bottom[3],
+                                                  vr_image* hdr, const vr_partition* part, const vr_shadow_binding* shadow)
+{
+    VR_REQUIRE(shadow, "shadow binding is NULL (use vr_deferred_light)");
+    return deferred_light(ctx, view, gb, lights, num_lights, amb_top, amb_bottom, hdr, part, shadow);
 }
 
 // ---- tiled deferred lighting for many point lights (BASELINE config 5) ---------------------------

@@ -235,6 +235,73 @@ extern "C" VR_API int vr_view_from_camera(const float eye[3], const float target
     return VR_OK;
 }
 
+// ---- shadow view (row f1) ---------------------------------------------------------------
+extern "C" VR_API void vr_shadow_default_params(vr_shadow_params* p, float world_size)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->resolution = 2048;                                            // Renderer.cpp:83
+    p->max_shadow_distance = world_size;                             // :349
+    p->light_space_z_up = world_size; p->light_space_z_down = world_size;   // :350-352
+    p->depth_bias = 0.0f;
+}
+
+// CascadedShadowMap::SetupForPlanarViewStable(light, projectionFrustum, inverseViewMatrix, maxShadowDistance,
+// zUp, zDown, 4.0f, 0, 1) (Renderer.cpp:345-352) [DONUT-RECOLLECTION]: with one cascade the split exponent has
+// nothing to split; the cascade is the bounding sphere of the camera frustum slice [0, maxShadowDistance],
+// snapped to whole shadow texels in light space, under an orthographic D3D projection.
+extern "C" VR_API int vr_shadow_view_setup(const vr_light* light, const vr_view* cam, const vr_shadow_params* p, vr_view* o)
+{
+    VR_REQUIRE(light && cam && p && o, "NULL argument");
+    VR_REQUIRE(light->type == VR_LIGHT_DIRECTIONAL, "the cascaded shadow map belongs to a directional light (Renderer.cpp:336)");
+    VR_REQUIRE(p->resolution >= 16 && p->resolution <= 16384 && p->max_shadow_distance > 0.0f
+               && p->light_space_z_up + p->light_space_z_down > 0.0f, "bad shadow parameters");
+    VR_REQUIRE(cam->view_to_clip[0] != 0.0f && cam->view_to_clip[5] != 0.0f, "camera projection is degenerate");
+    memset(o, 0, sizeof(*o));
+    const float* W = cam->world_to_view;
+    const V3 fwd = { W[2], W[6], W[10] };
+    const float d = p->max_shadow_distance;
+    const float hw = d / cam->view_to_clip[0], hh = d / cam->view_to_clip[5];
+    const float r2 = hw * hw + hh * hh;
+    float c = (d * d + r2) / (2.0f * d);
+    if (c > d) c = d;
+    const float radius = sqrtf((d - c) * (d - c) + r2);
+    const V3 centre = { cam->camera_pos[0] + fwd.x * c, cam->camera_pos[1] + fwd.y * c, cam->camera_pos[2] + fwd.z * c };
+    const V3 zl = normalized({ light->direction[0], light->direction[1], light->direction[2] });
+    VR_REQUIRE(dot(zl, zl) > 0.0f, "light direction is zero");
+    V3 up = { 0.0f, 1.0f, 0.0f };
+    if (fabsf(zl.y) > 0.99f) up = { 0.0f, 0.0f, 1.0f };
+    const V3 xl = normalized(cross(up, zl));
+    const V3 yl = cross(zl, xl);
+    const float texel = (2.0f * radius) / (float)p->resolution;
+    const float cx = floorf(dot(centre, xl) / texel) * texel, cy = floorf(dot(centre, yl) / texel) * texel;
+    const float cz = dot(centre, zl) - p->light_space_z_up;
+    const V3 origin = { (xl.x * cx + yl.x * cy) + zl.x * cz, (xl.y * cx + yl.y * cy) + zl.y * cz, (xl.z * cx + yl.z * cy) + zl.z * cz };
+    float* m = o->world_to_view;
+    const float x3[3] = { xl.x, xl.y, xl.z }, y3[3] = { yl.x, yl.y, yl.z }, z3[3] = { zl.x, zl.y, zl.z };
+    for (int i = 0; i < 3; i++) { m[i * 4 + 0] = x3[i]; m[i * 4 + 1] = y3[i]; m[i * 4 + 2] = z3[i]; m[i * 4 + 3] = 0.0f; }
+    const V3 no = { -origin.x, -origin.y, -origin.z };
+    m[12] = dot(no, xl); m[13] = dot(no, yl); m[14] = dot(no, zl); m[15] = 1.0f;
+    float* q = o->view_to_clip;
+    q[0] = 1.0f / radius; q[5] = 1.0f / radius; q[10] = 1.0f / (p->light_space_z_up + p->light_space_z_down); q[15] = 1.0f;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++)
+        o->world_to_clip[i * 4 + j] = ((m[i * 4 + 0] * q[0 * 4 + j] + m[i * 4 + 1] * q[1 * 4 + j]) + m[i * 4 + 2] * q[2 * 4 + j]) + m[i * 4 + 3] * q[3 * 4 + j];
+    if (!invert4x4(o->world_to_clip, o->clip_to_world)) { vr_set_error("singular shadow view-projection"); return VR_ERR_INVALID_ARGUMENT; }
+    o->camera_pos[0] = origin.x; o->camera_pos[1] = origin.y; o->camera_pos[2] = origin.z; o->camera_pos[3] = 1.0f;
+    const float* cc = o->world_to_clip;
+    plane_from(o->planes[0], -cc[2], -cc[6], -cc[10], cc[14]);
+    plane_from(o->planes[1], -cc[3] + cc[2], -cc[7] + cc[6], -cc[11] + cc[10], cc[15] - cc[14]);
+    plane_from(o->planes[2], -cc[3] - cc[0], -cc[7] - cc[4], -cc[11] - cc[8], cc[15] + cc[12]);
+    plane_from(o->planes[3], -cc[3] + cc[0], -cc[7] + cc[4], -cc[11] + cc[8], cc[15] - cc[12]);
+    plane_from(o->planes[4], -cc[3] + cc[1], -cc[7] + cc[5], -cc[11] + cc[9], cc[15] - cc[13]);
+    plane_from(o->planes[5], -cc[3] - cc[1], -cc[7] - cc[5], -cc[11] - cc[9], cc[15] + cc[13]);
+    o->viewport_x = 0; o->viewport_y = 0; o->viewport_w = p->resolution; o->viewport_h = p->resolution;
+    const float det = xl.x * (yl.y * zl.z - yl.z * zl.y) - yl.x * (xl.y * zl.z - xl.z * zl.y) + zl.x * (xl.y * yl.z - xl.z * yl.y);
+    o->mirrored = det < 0.0f ? 1 : 0;
+    o->reverse_depth = 0;
+    return VR_OK;
+}
+
 // ---- G-buffer (RenderTargets::Init / Clear; Renderer.h:60-101, Renderer.cpp:382) --------
 extern "C" VR_API int vr_gbuffer_create(vr_context* ctx, int32_t w, int32_t h, vr_gbuffer** out)
 {

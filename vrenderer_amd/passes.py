@@ -122,7 +122,9 @@ def spot_light(position, direction, intensity, light_range, inner_angle_deg, out
 
 def reference_sun():
     """The "Sun" Renderer::SceneLoaded creates (Renderer.cpp:133-146)."""
-    return directional_light((-0.9, -0.25, 0.35), irradiance=1.0, angular_size_deg=0.53)
+    l = directional_light((-0.9, -0.25, 0.35), irradiance=1.0, angular_size_deg=0.53)
+    l.out_of_bounds_shadow = 1.0        # LightConstants::outOfBoundsShadow: lit outside the shadow map
+    return l
 
 
 class RenderTargets:
@@ -396,12 +398,63 @@ class DeferredLightingPass:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None):
+    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None, shadow_map=None,
+               shadow_light_index=0):
+        """shadow_map: a CascadedShadowMap whose light view was set up and rendered this frame
+        (DirectionalLight::shadowMap, Renderer.cpp:336)."""
         n = len(lights)
         arr = (Light * max(n, 1))(*lights)
-        check(self.ctx.lib.vr_deferred_light(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
-                                             _f3(ambient_top), _f3(ambient_bottom), output.handle,
-                                             C.byref(partition) if partition is not None else None), "vr_deferred_light")
+        part = C.byref(partition) if partition is not None else None
+        if shadow_map is None:
+            check(self.ctx.lib.vr_deferred_light(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
+                                                 _f3(ambient_top), _f3(ambient_bottom), output.handle, part), "vr_deferred_light")
+            return
+        sb = capi.ShadowBinding(C.cast(C.pointer(shadow_map.view), C.c_void_p), shadow_map.targets.handle, shadow_light_index,
+                                shadow_map.params.depth_bias)
+        check(self.ctx.lib.vr_deferred_light_shadowed(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
+                                                      _f3(ambient_top), _f3(ambient_bottom), output.handle, part, C.byref(sb)),
+              "vr_deferred_light_shadowed")
+
+
+def default_shadow_params(world_size=2048.0, **kw):
+    """CascadedShadowMap(device, 2048, 1, 0, fmt) + the arguments of SetupForPlanarViewStable (Renderer.cpp:83,345-352)."""
+    p = capi.ShadowParams()
+    capi.load_library().vr_shadow_default_params(C.byref(p), world_size)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class CascadedShadowMap:
+    """donut::render::CascadedShadowMap with one cascade, as the reference uses it (Renderer.cpp:83-87, 333-367):
+    SetupForPlanarViewStable -> Clear -> TerrainPass.Render(depthOnly) into it -> lighting."""
+
+    def __init__(self, ctx, params):
+        self.ctx, self.params = ctx, params
+        self.targets = RenderTargets(ctx).Init(params.resolution, params.resolution)     # m_ShadowFramebuffer (depth plane)
+        self.view = View()
+
+    def SetupForPlanarViewStable(self, light, camera_view):
+        check(self.ctx.lib.vr_shadow_view_setup(C.byref(light), C.byref(camera_view), C.byref(self.params), C.byref(self.view)),
+              "vr_shadow_view_setup")
+        return self.view
+
+    def GetView(self):
+        return self.view
+
+    def Clear(self):
+        self.targets.Clear()
+
+    def RenderTerrain(self, terrain_pass, max_height=400.0, lock_view=0):
+        """The "Terrain Shadow" scope (Renderer.cpp:356-372): depthOnly render from the light's view."""
+        rp = default_render_params(max_height, depth_only=1, assume_cleared=1, lock_view=lock_view)
+        terrain_pass.Render(self.view, self.view, self.targets, rp)
+
+    def download_depth(self):
+        return self.targets.download("depth")
+
+    def close(self):
+        self.targets.close()
 
 
 class TiledDeferredLightingPass(DeferredLightingPass):
