@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, packed tiles, all-gather, de-tile) even with one rank")
+    ap.add_argument("--shadows", action="store_true",
+                    help="add row f1 to every step: the 2048^2 terrain shadow pass from the sun + the PCF shadow term in the "
+                         "lighting pass (Renderer.cpp:333-367); not part of the default workload")
     ap.add_argument("--exchange", choices=["ldr", "hdr"], default="ldr",
                     help="N>1: what the all-gather carries. ldr (default): each rank tone-maps its tiles (ToneMappingPass, "
                          "histogram all-reduced over the ranks) and RGB8 tiles are gathered, 3 B/px; hdr: RGB16F tiles, 6 B/px")
@@ -150,6 +153,9 @@ def main():
     deferred = vr.DeferredLightingPass(ctx)
     rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
 
+    shadow_map = None
+    if args.shadows:
+        shadow_map = vr.CascadedShadowMap(ctx, vr.default_shadow_params(float(size), depth_bias=0.002))
     part = None
     ctx_comm = ctx
     if use_dist:
@@ -225,18 +231,21 @@ def main():
 
     def step(i):
         v, vnext = views[i % 120], views[(i + 1) % 120]
+        if shadow_map is not None:                  # every rank renders the whole (small) shadow map
+            shadow_map.SetupForPlanarViewStable(lights[0], v)
+            shadow_map.RenderTerrain(tp)
         if not use_dist:
             tp.Render(v, v, rt, rp, None)
-            if not args.no_prepare:
+            if not args.no_prepare and shadow_map is None:
                 tp.Prepare(vnext, rt, rp, None)      # frame i+1's geometry is built under frame i's tile pass
-            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, None)
+            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, None, shadow_map=shadow_map)
             return
         b = i % nbuf
         main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
         tp.Render(v, v, rt, rp, part)
-        if not args.no_prepare:
+        if not args.no_prepare and shadow_map is None:
             tp.Prepare(vnext, rt, rp, part)
-        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_bufs[b], part)
+        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_bufs[b], part, shadow_map=shadow_map)
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
@@ -291,7 +300,10 @@ def main():
         got = frame.download()
         ref_img = vr.HdrImage(ctx, W, H)
         tp.Render(last, last, rt, rp, None)
-        deferred.Render(last, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, ref_img, None)
+        if shadow_map is not None:
+            shadow_map.SetupForPlanarViewStable(lights[0], last)
+            shadow_map.RenderTerrain(tp)
+        deferred.Render(last, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, ref_img, None, shadow_map=shadow_map)
         if use_dist and ldr:
             tm_ref = vr.ToneMappingPass(ctx)
             tm_ref.AdvanceFrame(1.0 / 60.0)
@@ -346,6 +358,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
+                                   + ("; +terrain shadow pass 2048^2 and PCF shadow term" if args.shadows else "")
                                    + (("+tone map (histogram all-reduce)+all-gather of RGB8 tiles+detile" if ldr else
                                        "+all-gather of RGB16F tiles+detile") if use_dist else ""),
                        "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,

@@ -8,6 +8,7 @@
 //                                                                      ClearSelectedNodes, GetNumLods, GetLodRanges)
 //   vRenderer::RenderTargets    source/Renderer.h:50-110              (Init, Clear, IsUpdateRequired)
 //   DeferredLightingPass        as called at source/Renderer.cpp:239-240,417-428 (Render(view, Inputs))
+//   CascadedShadowMap           as called at source/Renderer.cpp:83-87,333-372 (SetupForPlanarViewStable, Clear, GetView)
 //   ToneMappingPass             as called at source/Renderer.cpp:188-189,256-257,430-431 (AdvanceFrame, SimpleRender)
 // Like the reference, nothing here throws: methods return bool / log through a callback
 // (donut::log in the reference, TerrainPass.cpp:224-227, QuadTree.cpp:39).
@@ -194,6 +195,32 @@ namespace vRenderer
         vr_terrain* Get() const { return m_Terrain; }
     };
 
+    // donut::render::CascadedShadowMap with the one cascade the reference creates (Renderer.cpp:83-87)
+    class CascadedShadowMap
+    {
+        Device& m_Device;
+        RenderTargets m_Targets;           // m_ShadowFramebuffer: only the depth plane is used
+        vr_shadow_params m_Params;
+        vr_view m_View{};
+    public:
+        CascadedShadowMap(Device& device, int resolution, float worldSize) : m_Device(device)
+        {
+            vr_shadow_default_params(&m_Params, worldSize);
+            m_Params.resolution = resolution;
+            m_Targets.Init(device, resolution, resolution);
+        }
+        vr_shadow_params& Params() { return m_Params; }
+        // SetupForPlanarViewStable(light, projectionFrustum, inverseViewMatrix, maxShadowDistance, zUp, zDown, exponent, 0, 1)
+        bool SetupForPlanarViewStable(const vr_light& light, const vr_view& cameraView)
+        {
+            return Check(vr_shadow_view_setup(&light, &cameraView, &m_Params, &m_View), "vr_shadow_view_setup");
+        }
+        void Clear() { m_Targets.Clear(); }                                                   // Renderer.cpp:354
+        const vr_view& GetView() const { return m_View; }
+        RenderTargets& Framebuffer() { return m_Targets; }
+        vr_shadow_binding Binding(int lightIndex) { return vr_shadow_binding{ &m_View, m_Targets.GBufferFramebuffer(), lightIndex, m_Params.depth_bias }; }
+    };
+
     // donut::render::DeferredLightingPass as used at Renderer.cpp:239-240,417-428
     class DeferredLightingPass
     {
@@ -205,6 +232,8 @@ namespace vRenderer
             float ambientColorTop[3] = { 0, 0, 0 };
             float ambientColorBottom[3] = { 0, 0, 0 };
             const std::vector<vr_light>* lights = nullptr;
+            CascadedShadowMap* shadowMap = nullptr;                 // DirectionalLight::shadowMap (Renderer.cpp:336)
+            int shadowLightIndex = 0;
             vr_image* output = nullptr;                             // HdrColor
             void SetGBuffer(RenderTargets& targets) { gbuffer = &targets; output = targets.HdrColor(); }
         };
@@ -215,6 +244,12 @@ namespace vRenderer
         {
             static const std::vector<vr_light> none;
             const std::vector<vr_light>& l = inputs.lights ? *inputs.lights : none;
+            if (inputs.shadowMap) {
+                const vr_shadow_binding sb = inputs.shadowMap->Binding(inputs.shadowLightIndex);
+                return Check(vr_deferred_light_shadowed(m_Device.Get(), &view, inputs.gbuffer->GBufferFramebuffer(), l.data(), (int32_t)l.size(),
+                                                        inputs.ambientColorTop, inputs.ambientColorBottom, inputs.output, partition, &sb),
+                             "vr_deferred_light_shadowed");
+            }
             return Check(vr_deferred_light(m_Device.Get(), &view, inputs.gbuffer->GBufferFramebuffer(), l.data(), (int32_t)l.size(),
                                            inputs.ambientColorTop, inputs.ambientColorBottom, inputs.output, partition),
                          "vr_deferred_light");

@@ -1,6 +1,6 @@
 // A frame through the C++ host mirror (include/vrterrain.hpp), written the way the reference's
 // Renderer drives the path: Renderer::Renderer (Renderer.cpp:51-66,97), RenderScene (:207-224),
-// RecordCommand (:382, :401-415, :417-428, :430-431).  Compiled with g++ by tests/test_abi_cpu.py (the header
+// RecordCommand (:333-372, :382, :401-415, :417-428, :430-431).  Compiled with g++ by tests/test_abi_cpu.py (the header
 // is valid C++ and the library links) and run on the GPU box by tests/test_gpu_parity.py.
 #include <vrterrain.hpp>
 
@@ -51,6 +51,16 @@ int main(int argc, char** argv)
 
     // RecordCommand
     EditorParams editorParams;
+    lights[0].out_of_bounds_shadow = 1.0f;
+    CascadedShadowMap shadowMap(device, 512, (float)size);                         // Renderer.cpp:83 (2048 there)
+    shadowMap.Params().depth_bias = 0.002f;
+    {                                                                              // "Cascade ShadowMap", :333-372
+        if (!shadowMap.SetupForPlanarViewStable(lights[0], view)) return 2;
+        shadowMap.Clear();
+        TerrainPass::RenderParams shadowParams;
+        shadowParams.depthOnly = true;
+        if (!terrainPass.Render(shadowMap.GetView(), &shadowMap.GetView(), shadowMap.Framebuffer(), shadowParams, editorParams)) return 2;
+    }
     renderTargets.Clear();                                                         // :382
     if (editorParams.m_RenderTerrain) {                                            // :401-415
         TerrainPass::RenderParams renderParams;
@@ -67,6 +77,7 @@ int main(int argc, char** argv)
         const float k[3] = { 0.3f, 0.4f, 0.3f };
         for (int c = 0; c < 3; c++) deferredInputs.ambientColorBottom[c] = deferredInputs.ambientColorTop[c] * k[c];
         deferredInputs.lights = &lights;
+        deferredInputs.shadowMap = &shadowMap;                                     // m_DirectionalLight->shadowMap, :336
         if (!deferredLightingPass.Render(view, deferredInputs)) return 2;
     }
     ToneMappingPass toneMappingPass(device);                                       // CreateRenderPasses, :256-257
