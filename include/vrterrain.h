@@ -194,7 +194,8 @@ VR_API int  vr_terrain_download_mip(vr_terrain* t, int which, int level, void* h
  * and m_HeightLoaded (QuadTree.h:70).  The reference wrote this and left its launch commented out
  * (QuadTree.cpp:46-51), so the default is "not loaded": cull boxes span y in [0, camera.y].  With
  * enable != 0 the per-node (position.y, extents.y) are computed and NodeSelect culls with
- * [min.y, max.y] * max_height (QuadTree.cpp:87-91); UpdateTransforms then carries them too. */
+ * [min.y, max.y] * max_height (QuadTree.cpp:87-91); UpdateTransforms then carries them too.
+ * enable == 0 returns to the tree as built (y = location.y, extents.y = 0, not loaded). */
 VR_API int  vr_terrain_update_heights(vr_terrain* t, int enable);
 /* test helper: (position.y, extents.y) of node ids [first, first+count) */
 VR_API int  vr_terrain_download_node_heights(vr_terrain* t, uint32_t first, uint32_t count, float* out);

@@ -52,6 +52,7 @@ def lib():
     L.orc_set_height.argtypes = [vp]
     L.orc_node_height.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float)]
     L.orc_set_height_loaded.argtypes = [vp, C.c_int]
+    L.orc_reset_height.argtypes = [vp]
     L.orc_node_heights.argtypes = [vp, vp, C.c_long]
     L.orc_view_from_camera.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float), C.c_float, C.c_float, C.c_float,
                                        C.c_int, C.c_int, P(View)]
@@ -181,8 +182,11 @@ class OracleTerrain:
 
     def set_height(self, loaded=True):
         """QuadTree::SetHeight over the whole tree + m_HeightLoaded (QuadTree.cpp:46-51,191-208)."""
-        lib().orc_set_height(self.handle)
-        lib().orc_set_height_loaded(self.handle, int(loaded))
+        if loaded:
+            lib().orc_set_height(self.handle)
+            lib().orc_set_height_loaded(self.handle, 1)
+        else:
+            lib().orc_reset_height(self.handle)       # what vr_terrain_update_heights(t, 0) stands for
 
     def node_heights(self):
         out = np.zeros((self.num_nodes, 2), np.float32)

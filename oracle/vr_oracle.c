@@ -474,6 +474,19 @@ void orc_set_height(orc_terrain* t) { for (int s = 0; s < t->num_surfaces; s++) 
 /* m_HeightLoaded = true is what the reference's (commented-out) async task sets after SetHeight
  * (QuadTree.cpp:46-51); NodeSelect then culls with the node's real y-bounds (:87-91). */
 void orc_set_height_loaded(orc_terrain* t, int loaded) { t->height_loaded = loaded; }
+/* Back to the tree as Split built it (y = location.y, extents.y = 0) with m_HeightLoaded = false: the state
+ * vr_terrain_update_heights(t, 0) stands for.  (The reference never leaves the loaded state once entered.) */
+static void reset_height(orc_node* n, float y)
+{
+    if (!n) return;
+    n->pos[1] = y; n->ext[1] = 0.0f;
+    for (int i = 0; i < 4; i++) reset_height(n->child[i], y);
+}
+void orc_reset_height(orc_terrain* t)
+{
+    for (int s = 0; s < t->num_surfaces; s++) reset_height(t->roots[s], t->p.location[1]);
+    t->height_loaded = 0;
+}
 static void dump_heights(const orc_node* n, float* out, long max_ids)
 {
     if (!n) return;

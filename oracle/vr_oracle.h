@@ -50,6 +50,7 @@ int    orc_select(orc_terrain* t, const vr_view* v, float max_height, int stub_f
 void   orc_set_height(orc_terrain* t);
 int    orc_node_height(const orc_terrain* t, uint32_t node_id, float* pos_y, float* ext_y);
 void   orc_set_height_loaded(orc_terrain* t, int loaded);            /* m_HeightLoaded */
+void   orc_reset_height(orc_terrain* t);                             /* tree as built, m_HeightLoaded = false */
 void   orc_node_heights(const orc_terrain* t, float* out, long max_ids);   /* (pos.y, ext.y) per node id */
 
 /* FirstPersonCamera::LookAt + perspProjD3DStyle + PlanarView::UpdateCache. */

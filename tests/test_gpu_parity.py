@@ -866,3 +866,54 @@ def test_shadowed_deferred_on_packed_tiles(scene256, oracle, gpu_ctx):
             assert np.array_equal(packed[lt, :hh, :ww], ref[y0:y0 + hh, x0:x0 + ww, :3]), (r, tile)
         buf.close()
     for o in (full, rt, sm): o.close()
+
+
+def test_random_camera_fuzz_bit_exact(scene256, oracle, gpu_ctx):
+    """48 seeded random views (positions inside, above, below and far outside the terrain; any direction;
+    rolled up-vectors; fields of view from 5 to 150 degrees; odd target sizes): node lists and all G-buffer planes
+    must equal the oracle's bit for bit on every one of them."""
+    rng = np.random.default_rng(20260104)
+    sizes = [(320, 180), (257, 131), (64, 64), (400, 96)]
+    ot, tp = scene256["ot"], scene256["tp"]
+    checked_pixels = 0
+    for it in range(48):
+        kind = it % 6
+        if kind == 0:      # hovering close above the surface
+            x, z = rng.uniform(-100, 100, 2)
+            hx, hz = int(np.clip(x + 128, 0, 255)), int(np.clip(z + 128, 0, 255))
+            eye = (x, float(scene256["h"][hz, hx]) / 255.0 * 400.0 + rng.uniform(0.2, 8.0), z)
+        elif kind == 1:    # far outside, high up
+            ang = rng.uniform(0, 2 * np.pi)
+            eye = (400 * np.cos(ang), rng.uniform(100, 600), 400 * np.sin(ang))
+        elif kind == 2:    # below the terrain
+            eye = (rng.uniform(-100, 100), rng.uniform(-50, 20), rng.uniform(-100, 100))
+        else:              # anywhere in a box around the world
+            eye = tuple(rng.uniform((-200, 0, -200), (200, 450, 200)))
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if kind in (0, 1):
+            d = np.array([-eye[0], -eye[1] * rng.uniform(0.2, 1.5), -eye[2]]) + rng.normal(size=3) * 20     # roughly at the terrain
+            d /= np.linalg.norm(d)
+        tgt = tuple(np.array(eye) + d * 50.0)
+        up = rng.normal(size=3) if it % 4 == 3 else np.array([0.0, 1.0, 0.0])
+        if abs(np.dot(up / np.linalg.norm(up), d)) > 0.95:
+            up = np.array([1.0, 0.0, 0.0])
+        w, h = sizes[it % len(sizes)]
+        fov = float(rng.choice([5.0, 30.0, 60.0, 90.0, 150.0]))
+        v = vr.make_view(eye, tgt, w, h, vfov_deg=fov, up=tuple(up))
+        rp = vr.default_render_params(400.0, assume_cleared=1, wireframe=int(it % 7 == 6))
+        n_o, ids_o, inst_o = ot.select(v, 400.0)
+        if n_o > scene256["tp"].params.max_instances:
+            continue
+        n_g, ids_g, inst_g = tp.NodeSelect(v, 400.0)
+        assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), (it, eye, tgt)
+        gb_o = oracle.GBufferHost(w, h)
+        ot.render(v, gb_o, rp, None)
+        rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+        tp.Render(v, v, rt, rp, None)
+        planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+        assert tp.render_stats()["flags"] == 0
+        rt.close()
+        _assert_gbuffer_equal(gb_o, planes, f"fuzz view {it}: eye {eye} target {tgt} up {tuple(up)} fov {fov} {w}x{h}")
+        checked_pixels += int((planes["depth"] < 1.0).sum())
+    assert checked_pixels > 200000

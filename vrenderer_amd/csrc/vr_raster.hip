@@ -617,6 +617,12 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
 }
 
+// Low half of a visibility-buffer word: ~(key + 1), so a later bin entry (larger key) gives a SMALLER word and
+// wins ties at equal depth (ds_min), and no entry - not even key 0, the first triangle of the first node -
+// collides with 0xffffffff, the "nothing drawn" value.
+__device__ __forceinline__ uint32_t order_of(uint32_t key) { return ~(key + 1u); }
+__device__ __forceinline__ uint32_t key_of(uint32_t order) { return ~order - 1u; }
+
 constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
 
 // Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
@@ -787,15 +793,15 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
             t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1, WIRE);
             if (WIRE && t.visible) {
-                wire_edge(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, ~key);
-                wire_edge(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, ~key);
-                wire_edge(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, ~key);
+                wire_edge(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
+                wire_edge(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
+                wire_edge(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
                 t.visible = false;          // covered; skip the fill sweeps
             }
         }
         valid = valid && t.visible;
         VR_PROF_MARK(1);
-        const uint32_t order = ~key;
+        const uint32_t order = order_of(key);
         // tile-relative form
         const int64_t e0 = edge_eval(t.A0, t.B0, t.C0, PX0, PY0), e1 = edge_eval(t.A1, t.B1, t.C1, PX0, PY0), e2 = edge_eval(t.A2, t.B2, t.C2, PX0, PY0);
         const int64_t sx0 = (int64_t)t.A0 * 256, sy0 = (int64_t)t.B0 * 256, sx1 = (int64_t)t.A1 * 256, sy1 = (int64_t)t.B1 * 256;
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             if (a.depth_only) continue;
             if (low != prev) {                                    // neighbours usually share the triangle
                 uint32_t i0, i1, i2;
-                entry_vertices(~low, hard_tris, hard_first, i0, i1, i2);
+                entry_vertices(key_of(low), hard_tris, hard_first, i0, i1, i2);
                 s0 = load_sv(verts, i0); s1 = load_sv(verts, i1); s2 = load_sv(verts, i2);
                 t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, WIRE);
                 td = tri_derivs(t);
