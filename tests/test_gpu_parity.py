@@ -868,27 +868,24 @@ def test_shadowed_deferred_on_packed_tiles(scene256, oracle, gpu_ctx):
     for o in (full, rt, sm): o.close()
 
 
-def test_random_camera_fuzz_bit_exact(scene256, oracle, gpu_ctx):
-    """48 seeded random views (positions inside, above, below and far outside the terrain; any direction;
-    rolled up-vectors; fields of view from 5 to 150 degrees; odd target sizes): node lists and all G-buffer planes
-    must equal the oracle's bit for bit on every one of them."""
-    rng = np.random.default_rng(20260104)
+def _fuzz_views(rng, n, heightmap, size):
+    """Seeded random views: positions inside, above, below and far outside the terrain; any direction; rolled
+    up-vectors; fields of view from 5 to 150 degrees; odd target sizes."""
     sizes = [(320, 180), (257, 131), (64, 64), (400, 96)]
-    ot, tp = scene256["ot"], scene256["tp"]
-    checked_pixels = 0
-    for it in range(48):
+    half, s = size / 2.0, size / 256.0
+    for it in range(n):
         kind = it % 6
         if kind == 0:      # hovering close above the surface
-            x, z = rng.uniform(-100, 100, 2)
-            hx, hz = int(np.clip(x + 128, 0, 255)), int(np.clip(z + 128, 0, 255))
-            eye = (x, float(scene256["h"][hz, hx]) / 255.0 * 400.0 + rng.uniform(0.2, 8.0), z)
+            x, z = rng.uniform(-0.4 * size, 0.4 * size, 2)
+            hx, hz = int(np.clip(x + half, 0, size - 1)), int(np.clip(z + half, 0, size - 1))
+            eye = (x, float(heightmap[hz, hx]) / 255.0 * 400.0 + rng.uniform(0.2, 8.0), z)
         elif kind == 1:    # far outside, high up
             ang = rng.uniform(0, 2 * np.pi)
-            eye = (400 * np.cos(ang), rng.uniform(100, 600), 400 * np.sin(ang))
+            eye = (1.6 * size * np.cos(ang), rng.uniform(100, 600), 1.6 * size * np.sin(ang))
         elif kind == 2:    # below the terrain
-            eye = (rng.uniform(-100, 100), rng.uniform(-50, 20), rng.uniform(-100, 100))
+            eye = (rng.uniform(-100, 100) * s, rng.uniform(-50, 20), rng.uniform(-100, 100) * s)
         else:              # anywhere in a box around the world
-            eye = tuple(rng.uniform((-200, 0, -200), (200, 450, 200)))
+            eye = tuple(rng.uniform((-0.8 * size, 0, -0.8 * size), (0.8 * size, 450, 0.8 * size)))
         d = rng.normal(size=3)
         d /= np.linalg.norm(d)
         if kind in (0, 1):
@@ -900,20 +897,70 @@ def test_random_camera_fuzz_bit_exact(scene256, oracle, gpu_ctx):
             up = np.array([1.0, 0.0, 0.0])
         w, h = sizes[it % len(sizes)]
         fov = float(rng.choice([5.0, 30.0, 60.0, 90.0, 150.0]))
-        v = vr.make_view(eye, tgt, w, h, vfov_deg=fov, up=tuple(up))
-        rp = vr.default_render_params(400.0, assume_cleared=1, wireframe=int(it % 7 == 6))
+        yield it, eye, tgt, tuple(up), fov, w, h
+
+
+@pytest.mark.parametrize("scene_name,views,seed", [("scene256", 48, 20260104), ("scene2048", 18, 7)])
+def test_random_camera_fuzz_bit_exact(scene_name, views, seed, request, oracle, gpu_ctx):
+    """Seeded random views with random render options (wireframe, depth-only, a rank of a 2..4-way tile
+    partition): node lists, instance data and all G-buffer planes must equal the oracle's bit for bit on
+    every one of them.  (This test found the bin-key-0 bug: the first triangle of the first node was never shaded.)"""
+    sc = request.getfixturevalue(scene_name)
+    rng = np.random.default_rng(seed)
+    opt = np.random.default_rng(seed + 1)
+    ot, tp = sc["ot"], sc["tp"]
+    checked_pixels = 0
+    for it, eye, tgt, up, fov, w, h in _fuzz_views(rng, views, sc["h"], sc["size"]):
+        v = vr.make_view(eye, tgt, w, h, vfov_deg=fov, up=up)
+        world = int(opt.integers(1, 5))
+        part = vr.Partition(int(opt.integers(0, world)), world) if world > 1 and it % 3 == 1 else None
+        rp = vr.default_render_params(400.0, assume_cleared=int(opt.integers(0, 2)), wireframe=int(it % 7 == 6),
+                                      depth_only=int(it % 11 == 10))
+        what = f"fuzz view {it}: eye {eye} target {tgt} up {up} fov {fov} {w}x{h} part {(part.rank, part.world_size) if part else None}"
         n_o, ids_o, inst_o = ot.select(v, 400.0)
-        if n_o > scene256["tp"].params.max_instances:
+        if n_o > tp.params.max_instances:
             continue
         n_g, ids_g, inst_g = tp.NodeSelect(v, 400.0)
-        assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), (it, eye, tgt)
+        assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), what
         gb_o = oracle.GBufferHost(w, h)
-        ot.render(v, gb_o, rp, None)
+        ot.render(v, gb_o, rp, part)
         rt = vr.RenderTargets(gpu_ctx).Init(w, h)
-        tp.Render(v, v, rt, rp, None)
+        tp.Render(v, v, rt, rp, part)
         planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
-        assert tp.render_stats()["flags"] == 0
+        assert tp.render_stats()["flags"] == 0, what
         rt.close()
-        _assert_gbuffer_equal(gb_o, planes, f"fuzz view {it}: eye {eye} target {tgt} up {tuple(up)} fov {fov} {w}x{h}")
+        _assert_gbuffer_equal(gb_o, planes, what)
         checked_pixels += int((planes["depth"] < 1.0).sum())
-    assert checked_pixels > 200000
+    assert checked_pixels > 3000 * views
+
+
+def test_tonemap_fuzz_all_half_values(oracle, gpu_ctx):
+    """HdrColor filled with random half bit patterns (every class: zeros, denormals, negatives, huge values, inf, NaN):
+    histogram, adapted luminance and SRGBA8 output must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(99)
+    w, h = 512, 256
+    p = vr.default_tonemap_params()
+    for trial in range(3):
+        img = rng.integers(0, 65536, size=(h, w, 4), dtype=np.uint16)
+        if trial == 1:       # mostly plausible radiance with a sprinkle of specials
+            img = np.abs(rng.normal(0.2, 0.3, size=(h, w, 4))).astype(np.float16).view(np.uint16)
+            special = rng.integers(0, h * w, 2000)
+            img.reshape(-1, 4)[special, rng.integers(0, 3, 2000)] = rng.choice(
+                np.array([0x7c00, 0xfc00, 0x7e00, 0x0001, 0x8001, 0x7bff, 0xfbff, 0x8000], np.uint16), 2000)
+        if trial == 2:       # every half value appears in the red channel
+            img[:, :, 0].reshape(-1)[:65536] = np.arange(65536, dtype=np.uint16)
+        hdr = vr.HdrImage(gpu_ctx, w, h)
+        hdr.upload(img)
+        tm_g, tm_o = vr.ToneMappingPass(gpu_ctx), oracle.ToneMapper()
+        ldr = vr.LdrImage(gpu_ctx, w, h)
+        tm_g.AdvanceFrame(0.02); tm_o.AdvanceFrame(0.02)
+        for _ in range(2):
+            tm_g.SimpleRender(p, hdr, ldr)
+            want = tm_o.SimpleRender(p, img)
+        hist, lum = tm_g.download()
+        assert np.array_equal(hist, tm_o.hist), trial
+        assert np.float32(lum).view(np.uint32) == np.float32(tm_o.adapted).view(np.uint32), (trial, lum, tm_o.adapted)
+        got = ldr.download()
+        mis = np.argwhere(got != want)
+        assert mis.size == 0, f"trial {trial}: {len(mis)} bytes differ, first {mis[:4].tolist()}: hdr {img[tuple(mis[0][:2])]} got {got[tuple(mis[0][:2])]} want {want[tuple(mis[0][:2])]}"
+        for o in (hdr, ldr, tm_g): o.close()
