@@ -581,6 +581,41 @@ def test_full_size_8k_properties(scene2048, gpu_ctx):
         o.close()
 
 
+def test_full_size_8k_frame_against_the_oracle(scene2048, oracle, gpu_ctx):
+    """One whole frame at BASELINE's full size (7680x4320, flythrough frame 30) against the CPU oracle: all 33.2 M
+    pixels of every G-buffer plane bit-exact, HDR per-channel RMS <= 1e-4 (the oracle needs ~20 s for it)."""
+    from bench import flythrough_camera
+    W, H = 7680, 4320
+    eye, tgt = flythrough_camera(30)
+    v = vr.make_view(eye, tgt, W, H)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    rt = vr.RenderTargets(gpu_ctx).Init(W, H)
+    scene2048["tp"].Render(v, v, rt, rp)
+    hdr = vr.HdrImage(gpu_ctx, W, H)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    gb = oracle.GBufferHost(W, H)
+    n_o = scene2048["ot"].render(v, gb, rp)
+    assert n_o == scene2048["tp"].num_chunks()
+    for name, ref in (("depth", gb.depth.view(np.uint32)), ("diffuse", gb.diffuse), ("specular", gb.specular),
+                      ("normals", gb.normals), ("emissive", gb.emissive)):
+        got = rt.download(name)
+        if name == "depth":
+            got = got.view(np.uint32)
+        assert np.array_equal(got, ref), f"8K {name}: {int((got != ref).sum())} entries differ"
+        del got
+    covered = int((gb.depth < 1.0).sum())
+    assert covered > 0.5 * W * H
+    ref = oracle.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    got = hdr.download().view(np.float16)
+    se = np.zeros(3)
+    for y0 in range(0, H, 540):                       # in slabs: keeps the float64 temporaries small
+        d = got[y0:y0 + 540, :, :3].astype(np.float64) - ref[y0:y0 + 540, :, :3].astype(np.float64)
+        se += (d * d).sum(axis=(0, 1))
+    rms = np.sqrt(se / (W * H))
+    assert (rms <= 1e-4).all(), rms
+    hdr.close(); rt.close()
+
+
 def test_prepared_geometry_is_equivalent(scene256, oracle, gpu_ctx):
     """vr_terrain_prepare only moves work in time: a prepared frame, a frame whose prepared geometry does
     not match (discarded) and a frame rendered on one stream all equal the oracle."""
