@@ -122,6 +122,8 @@ assert C.sizeof(Light) == 64
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvrterrain.so")
+if os.environ.get("VRTERRAIN_LIB"):          # development: A/B another build of the same library (tools/build_variant.py)
+    LIB_PATH = os.environ["VRTERRAIN_LIB"]
 
 # every symbol include/vrterrain.h declares
 EXPORTS = [
