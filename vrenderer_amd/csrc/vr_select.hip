@@ -401,10 +401,11 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_HIP(hipEventCreateWithFlags(&g.ev_raster_done, hipEventDisableTiming));
     }
     VR_HIP(hipStreamSynchronize(ctx->stream));
-    {   // lowest priority: geometry fills in around the lighting pass without taking its CUs away
+    {   // lowest priority: geometry fills in around the tile / lighting passes (highest priority measured the same:
+        // what delays these small kernels is LDS space on the CUs, not queue arbitration)
         int least = 0, greatest = 0;
         VR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        VR_HIP(hipStreamCreateWithPriority(&t->geo_stream, hipStreamNonBlocking, getenv("VR_GEO_PRIO_HIGH") ? greatest : least));
+        VR_HIP(hipStreamCreateWithPriority(&t->geo_stream, hipStreamNonBlocking, least));
     }
     VR_HIP(hipEventCreateWithFlags(&t->ev_main_dep, hipEventDisableTiming));
     VR_HIP(hipEventCreateWithFlags(&t->ev_raster_begin, hipEventDisableTiming));
