@@ -624,6 +624,7 @@ __device__ __forceinline__ uint32_t order_of(uint32_t key) { return ~(key + 1u);
 __device__ __forceinline__ uint32_t key_of(uint32_t order) { return ~order - 1u; }
 
 constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
+constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels when at least half of the wave's lanes hold an entry
 
 // Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
 // of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
@@ -812,7 +813,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         const bool fits32 = valid && llabs(e0) + span0 < lim && llabs(e1) + span1 < lim && llabs(e2) + span2 < lim;
         const int x0 = t.x0 - ox, y0 = t.y0 - oy, x1 = t.x1 - ox, y1 = t.y1 - oy;      // tile-local, inclusive
         const int bw = valid ? x1 - x0 + 1 : 0, bh = valid ? y1 - y0 + 1 : 0;
-        const bool small = valid && (bw * bh <= kSmallArea);
+        // One lane per triangle pays when the wave's lanes are mostly busy (dense bins: low resolutions, distant terrain);
+        // with a handful of entries per wave the cooperative sweep wins for anything but tiny boxes (measured: 1080p -20 %).
+        const int n_wave = __popcll(__ballot(valid));
+        const bool small = valid && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
         if (small) {
             if (fits32) sweep_small<int32_t>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, (int32_t)sx0, (int32_t)sy0, (int32_t)sx1, (int32_t)sy1,
                                              (int32_t)sx2, (int32_t)sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1, t.z0, t.dz1, t.dz2, t.inv_area, order);
