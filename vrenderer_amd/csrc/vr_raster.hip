@@ -624,7 +624,8 @@ __device__ __forceinline__ uint32_t order_of(uint32_t key) { return ~(key + 1u);
 __device__ __forceinline__ uint32_t key_of(uint32_t order) { return ~order - 1u; }
 
 constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
-constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels when at least half of the wave's lanes hold an entry
+constexpr int kDenseWave = 32, kSmallAreaDense = 128;
+constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)   // ... <= 128 pixels when at least half of the wave's lanes hold an entry
 
 // Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
 // of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
@@ -661,14 +662,15 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
                                           int b0, int b1, int b2, int x0, int y0, int x1, int y1,
                                           float z0, float dz1, float dz2, float ia, uint32_t ord)
 {
-    const int lx = lane & 7, ly = lane >> 3;
+    constexpr int BW = kSweepW, BH = 64 / kSweepW;                                                              // block of 64 pixels, one per lane
+    const int lx = lane & (BW - 1), ly = lane / BW;
     const T l0 = sx0 * (T)lx + sy0 * (T)ly, l1 = sx1 * (T)lx + sy1 * (T)ly, l2 = sx2 * (T)lx + sy2 * (T)ly;    // per-lane offsets
-    const T m0 = (sx0 > 0 ? sx0 * 7 : (T)0) + (sy0 > 0 ? sy0 * 7 : (T)0);                                      // max offset inside a block
-    const T m1 = (sx1 > 0 ? sx1 * 7 : (T)0) + (sy1 > 0 ? sy1 * 7 : (T)0);
-    const T m2 = (sx2 > 0 ? sx2 * 7 : (T)0) + (sy2 > 0 ? sy2 * 7 : (T)0);
-    for (int yb = y0 & ~7; yb <= y1; yb += 8) {
+    const T m0 = (sx0 > 0 ? sx0 * (BW - 1) : (T)0) + (sy0 > 0 ? sy0 * (BH - 1) : (T)0);                        // max offset inside a block
+    const T m1 = (sx1 > 0 ? sx1 * (BW - 1) : (T)0) + (sy1 > 0 ? sy1 * (BH - 1) : (T)0);
+    const T m2 = (sx2 > 0 ? sx2 * (BW - 1) : (T)0) + (sy2 > 0 ? sy2 * (BH - 1) : (T)0);
+    for (int yb = y0 & ~(BH - 1); yb <= y1; yb += BH) {
         const T r0 = e0 - (T)b0 + sy0 * (T)yb, r1 = e1 - (T)b1 + sy1 * (T)yb, r2 = e2 - (T)b2 + sy2 * (T)yb;
-        for (int xb = x0 & ~7; xb <= x1; xb += 8) {
+        for (int xb = x0 & ~(BW - 1); xb <= x1; xb += BW) {
             const T o0 = r0 + sx0 * (T)xb, o1 = r1 + sx1 * (T)xb, o2 = r2 + sx2 * (T)xb;                        // block origin (uniform)
             if (((o0 + m0) | (o1 + m1) | (o2 + m2)) < 0) continue;                                              // block outside an edge
             const T v0 = o0 + l0, v1 = o1 + l1, v2 = o2 + l2;
