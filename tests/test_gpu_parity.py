@@ -1051,3 +1051,29 @@ def test_deferred_fuzz_random_gbuffer_and_lights(scene256, oracle, gpu_ctx):
         assert (err > 1.5e-3 * np.abs(ref) + 1e-4).mean() < 1e-3, trial
         assert np.sqrt(np.mean((err / (np.abs(ref) + 1.0)) ** 2)) < 2e-4, trial
     hdr.close(); rt.close()
+
+
+def test_large_heightmap_8192(oracle, gpu_ctx):
+    """The largest surface the reference's LOD cap makes sense for (8192^2 texels, numLods = min(11, log2) = 11,
+    QuadTree.cpp:10-17): 335 MB of textures + quad tables on the device, frames bit-exact vs the oracle."""
+    size = 8192
+    h = vr.synth_heightmap(gpu_ctx, size)
+    a = vr.synth_albedo(gpu_ctx, size, h)
+    p = params(size)
+    tp = vr.TerrainPass(gpu_ctx, p).Init(h, a)
+    ot = oracle.OracleTerrain(p, h, a)
+    try:
+        assert tp.GetNumLods() == ot.num_lods == 11
+        sc = dict(ot=ot, tp=tp, size=size)
+        for cam in (0, 5):
+            eye, tgt = scaled_camera(CAMERAS[cam], size)
+            v, gb_o, planes, n_o, n_g = _render_both(sc, oracle, gpu_ctx, eye, tgt, 640, 360)
+            assert n_o == n_g and n_o > 0
+            _assert_gbuffer_equal(gb_o, planes, f"8192 camera {cam}")
+        # a camera close to the ground: deep LODs of the big tree
+        hgt = float(h[size // 2 + 40, size // 2 - 60]) / 255.0 * 400.0
+        v, gb_o, planes, n_o, n_g = _render_both(sc, oracle, gpu_ctx, (-60.0, hgt + 30.0, 40.0), (200.0, hgt - 40.0, -150.0), 640, 360)
+        assert n_o == n_g and n_o > 50
+        _assert_gbuffer_equal(gb_o, planes, "8192 close camera")
+    finally:
+        tp.close(); ot.close()
