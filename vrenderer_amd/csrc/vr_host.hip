@@ -510,8 +510,9 @@ int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part)
     for (int r = 0; r < world; r++) { int c = count_owned(tx, ty, r, world); if (c > max_owned) max_owned = c; }
     std::vector<int32_t> owned, slot((size_t)tx * ty), raster;
     std::vector<int> next(world, 0);
-    const int rtx = (w + kRasterTile - 1) / kRasterTile, rty = (h + kRasterTile - 1) / kRasterTile;
-    const int sub = VR_OWNER_TILE / kRasterTile;
+    const int rtile = 1 << vr_raster_tile_shift(w, h);
+    const int rtx = (w + rtile - 1) / rtile, rty = (h + rtile - 1) / rtile;
+    const int sub = VR_OWNER_TILE / rtile;
     for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++) {
         int o = (x + y) % world;
         slot[(size_t)y * tx + x] = o * max_owned + next[o]++;

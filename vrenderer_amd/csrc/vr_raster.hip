@@ -38,6 +38,7 @@ struct RasterArgs {
     int w, h;                       // render target size
     int vx0, vy0, vx1, vy1;         // inclusive pixel bounds (viewport ∩ target)
     int rtx, rty;                   // raster tiles per row / column
+    int tile_shift;                 // log2 of the raster tile edge (5 or 6)
     int mirrored;
     int world, rank;                // partition (world <= 1: whole frame)
     int depth_only, assume_cleared;
@@ -229,8 +230,8 @@ __device__ __forceinline__ TriSetup tri_setup(ScreenVert& s0, ScreenVert& s1, Sc
 __device__ __forceinline__ bool tile_owned(const RasterArgs& a, int tx, int ty)
 {
     if (a.world <= 1) return true;
-    const int sub = VR_OWNER_TILE / kRasterTile;
-    return ((tx / sub + ty / sub) % a.world) == a.rank;
+    const int sub_shift = 7 - a.tile_shift;                     // VR_OWNER_TILE = 128 = raster tile << sub_shift
+    return (((tx >> sub_shift) + (ty >> sub_shift)) % a.world) == a.rank;
 }
 
 __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1)
@@ -243,7 +244,7 @@ __device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVer
 {
     TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, a.wireframe != 0);
     if (!t.visible) return ~0ull;
-    return pack_rect(t.x0 / kRasterTile, t.y0 / kRasterTile, t.x1 / kRasterTile, t.y1 / kRasterTile);
+    return pack_rect(t.x0 >> a.tile_shift, t.y0 >> a.tile_shift, t.x1 >> a.tile_shift, t.y1 >> a.tile_shift);
 }
 
 // Adds `r`'s triangle to the per-tile counters (FILL = false) or claims its bin slots and writes
@@ -630,7 +631,7 @@ constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x
 // Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
 // of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
 // When every value over the tile fits in 32 bits the sweep runs in int32, else in int64.
-template <typename T>
+template <typename T, int TILE>
 __device__ __forceinline__ void cover_pixel(unsigned long long* __restrict__ vis, int lx, int ly, T v1, T v2, int b1, int b2,
                                             float z0, float dz1, float dz2, float ia, uint32_t ord)
 {
@@ -638,10 +639,10 @@ __device__ __forceinline__ void cover_pixel(unsigned long long* __restrict__ vis
     float z = (z0 + l1 * dz1) + l2 * dz2;
     if (!(z >= 0.0f && z <= 1.0f)) return;                       // depth clip
     z = z + 0.0f;                                                // canonical +0
-    atomicMin(&vis[ly * kRasterTile + lx], ((unsigned long long)__float_as_uint(z) << 32) | ord);
+    atomicMin(&vis[ly * TILE + lx], ((unsigned long long)__float_as_uint(z) << 32) | ord);
 }
 
-template <typename T>
+template <typename T, int TILE>
 __device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
                                             int b0, int b1, int b2, int x0, int y0, int x1, int y1,
                                             float z0, float dz1, float dz2, float ia, uint32_t ord)
@@ -649,7 +650,7 @@ __device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis
     for (int y = y0; y <= y1; y++) {
         T r0 = e0 + sy0 * (T)y - (T)b0 + sx0 * (T)x0, r1 = e1 + sy1 * (T)y - (T)b1 + sx1 * (T)x0, r2 = e2 + sy2 * (T)y - (T)b2 + sx2 * (T)x0;
         for (int x = x0; x <= x1; x++) {
-            if ((r0 | r1 | r2) >= 0) cover_pixel<T>(vis, x, y, r1, r2, b1, b2, z0, dz1, dz2, ia, ord);
+            if ((r0 | r1 | r2) >= 0) cover_pixel<T, TILE>(vis, x, y, r1, r2, b1, b2, z0, dz1, dz2, ia, ord);
             r0 += sx0; r1 += sx1; r2 += sx2;
         }
     }
@@ -657,7 +658,7 @@ __device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis
 
 // All 64 lanes sweep one (wave-uniform) triangle in 8x8 pixel blocks; blocks that lie
 // completely outside an edge are skipped with scalar arithmetic only.
-template <typename T>
+template <typename T, int TILE>
 __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, int lane, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
                                           int b0, int b1, int b2, int x0, int y0, int x1, int y1,
                                           float z0, float dz1, float dz2, float ia, uint32_t ord)
@@ -676,7 +677,7 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
             const T v0 = o0 + l0, v1 = o1 + l1, v2 = o2 + l2;
             const int x = xb + lx, y = yb + ly;
             if ((v0 | v1 | v2) < 0 || x < x0 || x > x1 || y < y0 || y > y1) continue;
-            cover_pixel<T>(vis, x, y, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
+            cover_pixel<T, TILE>(vis, x, y, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
         }
     }
 }
@@ -693,6 +694,7 @@ __device__ __forceinline__ int64_t floor_div64(int64_t num, int64_t den)
 // [min, max) of the major axis: the pixel that contains the exact line point there.  The pixel is a
 // sample of the triangle's plane at its centre (depth, attributes), so the resolve below is shared
 // with fill mode.  Debug mode: one lane per triangle, no wave cooperation.
+template <int TILE>
 __device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, const ScreenVert& va, const ScreenVert& vb, const TriSetup& t,
                                         int ox, int oy, int bx0, int by0, int bx1, int by1, uint32_t ord)
 {
@@ -716,7 +718,7 @@ __device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, con
         }
         const int32_t PX = px * 256 + 128, PY = py * 256 + 128;
         const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
-        cover_pixel<int64_t>(vis, px - ox, py - oy, E1, E2, 0, 0, t.z0, t.dz1, t.dz2, t.inv_area, ord);
+        cover_pixel<int64_t, TILE>(vis, px - ox, py - oy, E1, E2, 0, 0, t.z0, t.dz1, t.dz2, t.inv_area, ord);
     }
 }
 
@@ -742,7 +744,7 @@ extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
 #define VR_PROF_BEGIN do { } while (0)
 #endif
 
-template <bool WIRE>
+template <bool WIRE, int TILE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                                                  const float* __restrict__ lut_g, const float* __restrict__ thr_g,
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const)
 {
-    __shared__ unsigned long long vis[kRasterTile * kRasterTile];
+    __shared__ unsigned long long vis[TILE * TILE];
     __shared__ uint8_t enc[kEncTabSize + 3];
     __shared__ float lut[256];
     __shared__ float thr[256];
@@ -764,11 +766,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     for (int i = tid; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
-    const int ox = txi * kRasterTile, oy = tyi * kRasterTile;
+    const int ox = txi * TILE, oy = tyi * TILE;
     lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
-    for (int i = tid; i < kRasterTile * kRasterTile; i += 256) {
-        const int lx = i & (kRasterTile - 1), ly = i >> 6;
+    for (int i = tid; i < TILE * TILE; i += 256) {
+        const int lx = i & (TILE - 1), ly = i / TILE;
         const int gx = ox + lx, gy = oy + ly;
         unsigned long long key = 0ull;                         // outside the target: nothing passes
         if (gx < a.w && gy < a.h) {
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     VR_PROF_MARK(0);
 
     const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
-    const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + kRasterTile - 1, a.vx1), by1 = min(oy + kRasterTile - 1, a.vy1);
+    const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + TILE - 1, a.vx1), by1 = min(oy + TILE - 1, a.vy1);
     const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
     for (uint32_t base = 0; base < n; base += 256) {
         // consecutive bin entries go to different waves so that a short list still uses all four
@@ -796,9 +798,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
             t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1, WIRE);
             if (WIRE && t.visible) {
-                wire_edge(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
-                wire_edge(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
-                wire_edge(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
+                wire_edge<TILE>(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
+                wire_edge<TILE>(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
+                wire_edge<TILE>(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
                 t.visible = false;          // covered; skip the fill sweeps
             }
         }
@@ -820,9 +822,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         const int n_wave = __popcll(__ballot(valid));
         const bool small = valid && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
         if (small) {
-            if (fits32) sweep_small<int32_t>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, (int32_t)sx0, (int32_t)sy0, (int32_t)sx1, (int32_t)sy1,
+            if (fits32) sweep_small<int32_t, TILE>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, (int32_t)sx0, (int32_t)sy0, (int32_t)sx1, (int32_t)sy1,
                                              (int32_t)sx2, (int32_t)sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1, t.z0, t.dz1, t.dz2, t.inv_area, order);
-            else sweep_small<int64_t>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1,
+            else sweep_small<int64_t, TILE>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1,
                                       t.z0, t.dz1, t.dz2, t.inv_area, order);
         }
         VR_PROF_MARK(2);
@@ -841,11 +843,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
             const int tx0 = bx & 255u, ty0 = (bx >> 8) & 255u, tx1 = (bx >> 16) & 255u, ty1 = bx >> 24;
             if (m & 8u) {
-                sweep_big<int32_t>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC((int32_t)sx0), BC((int32_t)sy0),
+                sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC((int32_t)sx0), BC((int32_t)sy0),
                                    BC((int32_t)sx1), BC((int32_t)sy1), BC((int32_t)sx2), BC((int32_t)sy2), b0, b1, b2, tx0, ty0, tx1, ty1,
                                    z0, dz1, dz2, ia, ord);
             } else {
-                sweep_big<int64_t>(vis, lane, BC64(e0), BC64(e1), BC64(e2), BC64(sx0), BC64(sy0), BC64(sx1), BC64(sy1), BC64(sx2), BC64(sy2),
+                sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), BC64(sx0), BC64(sy0), BC64(sx1), BC64(sy1), BC64(sx2), BC64(sy2),
                                    b0, b1, b2, tx0, ty0, tx1, ty1, z0, dz1, dz2, ia, ord);
             }
 #undef BC64
@@ -858,8 +860,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
     const bool vec_ok = (a.w & 3) == 0;
-    for (int g = tid; g < kRasterTile * kRasterTile / 4; g += 256) {
-        const int ly = g >> 4, lx0 = (g & 15) * 4;
+    for (int g = tid; g < TILE * TILE / 4; g += 256) {
+        const int ly = g / (TILE / 4), lx0 = (g % (TILE / 4)) * 4;
         const int gy = oy + ly, gx0 = ox + lx0;
         if (gy >= a.h || gx0 >= a.w) continue;
         uint32_t covered = 0;
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         ScreenVert s0, s1, s2; TriSetup t; TriDeriv td;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long key = vis[ly * kRasterTile + lx0 + k];
+            const unsigned long long key = vis[ly * TILE + lx0 + k];
             const uint32_t low = (uint32_t)key;
             dep[k] = __uint_as_float((uint32_t)(key >> 32)); dif[k] = 0; nn0[k] = 0; nn1[k] = 0;
             if (low == 0xffffffffu || gx0 + k >= a.w) continue;
@@ -946,7 +948,8 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     if (a.vy0 < 0) a.vy0 = 0;
     if (a.vx1 > w - 1) a.vx1 = w - 1;
     if (a.vy1 > h - 1) a.vy1 = h - 1;
-    a.rtx = (w + kRasterTile - 1) / kRasterTile; a.rty = (h + kRasterTile - 1) / kRasterTile;
+    a.tile_shift = vr_raster_tile_shift(w, h);
+    { const int rt = 1 << a.tile_shift; a.rtx = (w + rt - 1) / rt; a.rty = (h + rt - 1) / rt; }
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared; a.wireframe = rp->wireframe ? 1 : 0;
     a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
@@ -1079,7 +1082,8 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER);
         const int32_t* tiles = whole ? (const int32_t*)nullptr : ctx->d_raster_tiles;
-        auto kern = a.wireframe ? k_raster<true> : k_raster<false>;
+        auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32> : k_raster<false, 32>)
+                                      : (a.wireframe ? k_raster<true, 64> : k_raster<false, 64>);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
