@@ -49,6 +49,26 @@ def test_defaults_are_the_reference_settings(product_lib):
     assert rp.max_height == 400.0 and not (rp.wireframe or rp.lock_view or rp.depth_only)   # Renderer.h:37-40
 
 
+def test_shadow_and_tonemap_defaults_and_argument_checks(product_lib, oracle):
+    assert C.sizeof(capi.ShadowParams) == 32 and C.sizeof(capi.TonemapParams) == 40 and C.sizeof(capi.ShadowBinding) == 24
+    sp = vr.default_shadow_params(2048.0)                      # CascadedShadowMap(device, 2048, 1, 0, fmt), WORLD_SIZE x3 (Renderer.cpp:83,349-352)
+    assert (sp.resolution, sp.max_shadow_distance, sp.light_space_z_up, sp.light_space_z_down, sp.depth_bias) == (2048, 2048.0, 2048.0, 2048.0, 0.0)
+    tm = vr.default_tonemap_params()                           # ToneMappingParameters() defaults
+    assert [round(getattr(tm, n), 4) for n, _ in capi.TonemapParams._fields_] == [0.8, 0.95, 1.0, 0.5, 0.02, 0.5, -0.5, 3.0, -10.0, 4.0]
+    cam = vr.make_view(DEFAULT_EYE, DEFAULT_TARGET, 1920, 1080)
+    sun, out = vr.reference_sun(), vr.View()
+    assert product_lib.vr_shadow_view_setup(C.byref(sun), C.byref(cam), C.byref(sp), C.byref(out)) == capi.VR_OK
+    assert bytes(out) == bytes(oracle.shadow_view(sun, cam, sp))                     # host code == restatement, every field
+    assert out.viewport_w == out.viewport_h == 2048 and out.view_to_clip[15] == 1.0 and out.view_to_clip[11] == 0.0   # orthographic
+    lamp = vr.point_light((0, 10, 0), 100.0, 50.0)
+    assert product_lib.vr_shadow_view_setup(C.byref(lamp), C.byref(cam), C.byref(sp), C.byref(out)) == capi.VR_ERR_INVALID_ARGUMENT
+    assert b"directional" in product_lib.vr_last_error()
+    bad = vr.default_shadow_params(2048.0, resolution=0)
+    assert product_lib.vr_shadow_view_setup(C.byref(sun), C.byref(cam), C.byref(bad), C.byref(out)) == capi.VR_ERR_INVALID_ARGUMENT
+    assert product_lib.vr_shadow_view_setup(None, C.byref(cam), C.byref(sp), C.byref(out)) == capi.VR_ERR_INVALID_ARGUMENT
+    assert product_lib.vr_partition_packed_bytes_ldr(7680, 4320, 8) * 2 == product_lib.vr_partition_packed_bytes(7680, 4320, 8)
+
+
 def test_view_helper_matches_oracle_bit_for_bit(product_lib, oracle):
     for (w, h) in ((1920, 1080), (7680, 4320), (333, 777)):
         for eye, tgt in ((DEFAULT_EYE, DEFAULT_TARGET), ((600.0, 250.0, 0.0), (0.0, 0.0, 0.0)), ((3.0, 9.0, -4.0), (100.0, 0.0, 50.0))):
