@@ -466,7 +466,9 @@ extern "C" VR_API int vr_deferred_light_shadowed(vr_context* ctx, const vr_view*
 // all-lights loop of the oracle.
 constexpr int kLightTile = 32;
 constexpr int kTileLightCap = 1024;
-struct TiledLight { float vec[3]; float inv_range; float color[3]; float intensity; float cosH, sinH, tanH; int type; };
+// 32 B per staged light (4 workgroups of 1024 lights fit a CU's LDS): colour premultiplied by the intensity;
+// w = 0 for a point light, 1 + half angular size for a directional one (its cos/sin/tan are then taken per pixel).
+struct TiledLight { float vec[3]; float inv_range; float color[3]; float w; };
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
@@ -580,8 +582,8 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
                 TiledLight t;
                 const float* v = L.type == VR_LIGHT_DIRECTIONAL ? L.dir : L.pos;
                 t.vec[0] = v[0]; t.vec[1] = v[1]; t.vec[2] = v[2]; t.inv_range = L.inv_range;
-                t.color[0] = L.color[0]; t.color[1] = L.color[1]; t.color[2] = L.color[2]; t.intensity = L.intensity;
-                t.cosH = L.cosH; t.sinH = L.sinH; t.tanH = L.tanH; t.type = L.type;
+                t.color[0] = L.color[0] * L.intensity; t.color[1] = L.color[1] * L.intensity; t.color[2] = L.color[2] * L.intensity;
+                t.w = L.type == VR_LIGHT_DIRECTIONAL ? 1.0f + atan2f(L.sinH, L.cosH) : 0.0f;
                 s_light[slot] = t;
             } else atomicOr(overflow_flag, 1u);
         }
@@ -601,7 +603,12 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
         if (depth[k] < 1.0f) {
             for (uint32_t i = 0; i < n; i++) {
                 const TiledLight& t = s_light[i];
-                add_light(s, t.type, t.vec, t.inv_range, t.color, t.intensity, t.cosH, t.sinH, t.tanH, diffuseTerm, specularTerm);
+                if (t.w > 0.0f) {                                  // directional (block-uniform branch)
+                    const float half = t.w - 1.0f, ch = __cosf(half), sh = __sinf(half);
+                    add_light(s, VR_LIGHT_DIRECTIONAL, t.vec, 0.0f, t.color, 1.0f, ch, sh, sh * fast_rcp(ch), diffuseTerm, specularTerm);
+                } else {
+                    add_light(s, VR_LIGHT_POINT, t.vec, t.inv_range, t.color, 1.0f, 1.0f, 0.0f, 0.0f, diffuseTerm, specularTerm);
+                }
             }
         }
         float rgb[3];
