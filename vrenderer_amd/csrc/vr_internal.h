@@ -164,6 +164,7 @@ struct vr_terrain {
     int cur = 0;                            // set of the most recent select / render
     // QuadTree::SetHeight results: (position.y, extents.y) per node id; m_HeightLoaded
     float2* d_node_heights = nullptr;
+    uchar2* d_minmax = nullptr;          // raw (min, max) bytes per node of one surface: scratch of the mip-style SetHeight
     bool height_loaded = false;
     float texel_size[2] = { 0.0f, 0.0f };   // m_TexelSize (QuadTree.cpp:29)
     int surfaces_per_side = 1;              // WORLD_SIZE / SURFACE_SIZE (TerrainPass.cpp:97)

@@ -292,6 +292,52 @@ __global__ __launch_bounds__(256) void k_node_heights_thread(HeightArgs a, const
     }
 }
 
+// Mip-style path (the usual case: a power-of-two surface sampled one texel per world unit): every node's texel
+// rectangle is then an exact dyadic square and the four children tile their parent, so the raw (min, max) bytes of a
+// level follow from the level below; the reference's "max == min => min = 0" quirk and the float conversion are
+// applied per node on the way out (finish_minmax), which keeps the result identical to the per-node scan.
+__global__ __launch_bounds__(256) void k_minmax_leaf(const uint8_t* __restrict__ tex, int tex_w, int rx0, int ry0, uint32_t n, int s,
+                                                      uchar2* __restrict__ mm, float2* __restrict__ out)
+{
+    const uint64_t total = (uint64_t)n * n;
+    for (uint64_t node = (uint64_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (uint64_t)gridDim.x * 256) {
+        const uint32_t ix = (uint32_t)(node % n), iz = (uint32_t)(node / n);
+        const uint8_t* p = tex + (size_t)(ry0 + (int)iz * s) * tex_w + (rx0 + (int)ix * s);
+        int mn = 256, mx = -1;
+        for (int j = 0; j < s; j++) for (int i = 0; i < s; i++) { const int b = p[(size_t)j * tex_w + i]; mn = min(mn, b); mx = max(mx, b); }
+        mm[node] = make_uchar2((unsigned char)mn, (unsigned char)mx);
+        out[node] = finish_minmax(mn, mx);
+    }
+}
+__global__ __launch_bounds__(256) void k_minmax_up(const uchar2* __restrict__ child, uint32_t n, uchar2* __restrict__ mm, float2* __restrict__ out)
+{
+    const uint64_t total = (uint64_t)n * n;
+    for (uint64_t node = (uint64_t)blockIdx.x * 256 + threadIdx.x; node < total; node += (uint64_t)gridDim.x * 256) {
+        const uint32_t ix = (uint32_t)(node % n), iz = (uint32_t)(node / n);
+        const uchar2* c = child + (size_t)(2u * iz) * (2u * n) + 2u * ix;
+        const uchar2 a0 = c[0], a1 = c[1], a2 = c[2u * n], a3 = c[2u * n + 1];
+        const int mn = min(min((int)a0.x, (int)a1.x), min((int)a2.x, (int)a3.x)), mx = max(max((int)a0.y, (int)a1.y), max((int)a2.y, (int)a3.y));
+        mm[node] = make_uchar2((unsigned char)mn, (unsigned char)mx);
+        out[node] = finish_minmax(mn, mx);
+    }
+}
+
+// texel origin of a surface's root if the mip-style path applies to it, else false
+static bool dyadic_root(const vr_terrain* t, const float loc[3], int* rx0, int* ry0, int* leaf_texels)
+{
+    const float S = t->p.surface_size;
+    if (t->texel_size[0] != 1.0f || t->texel_size[1] != 1.0f) return false;
+    if (!(S >= 1.0f) || S != floorf(S) || ((int)S & ((int)S - 1)) != 0) return false;
+    if ((int64_t)t->height.w0 * t->height.h0 > (1 << 24)) return false;       // GetHeightValue indexes in float: exact only up to 2^24
+    const float minx = (loc[0] - S / 2) + t->p.world_size / 2, miny = (loc[2] - S / 2) + t->p.world_size / 2;
+    if (minx != floorf(minx) || miny != floorf(miny)) return false;
+    if (minx < 0.0f || miny < 0.0f || minx + S > (float)t->height.w0 || miny + S > (float)t->height.h0) return false;
+    const int s = (int)S >> t->num_lods;
+    if (s < 1 || (s << t->num_lods) != (int)S) return false;
+    *rx0 = (int)minx; *ry0 = (int)miny; *leaf_texels = s;
+    return true;
+}
+
 extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
 {
     VR_REQUIRE(t != nullptr, "terrain is NULL");
@@ -312,6 +358,22 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
         a.loc[0] = t->p.location[0] + x * t->p.surface_size; a.loc[1] = t->p.location[1] + 0.0f; a.loc[2] = t->p.location[2] + y * t->p.surface_size;
     }
     float2* out = t->d_node_heights + (size_t)surf * nodes;
+    int rx0 = 0, ry0 = 0, leaf = 0;
+    if (dyadic_root(t, a.loc, &rx0, &ry0, &leaf)) {
+        if (!t->d_minmax) VR_HIP(hipMalloc(&t->d_minmax, nodes * sizeof(uchar2)));
+        for (int d = t->num_lods; d >= 0; d--) {
+            const uint32_t n = 1u << d;
+            const uint64_t base = ((((uint64_t)1 << (2 * d)) - 1) / 3), cells = (uint64_t)n * n, blocks = (cells + 255) / 256;
+            const unsigned grid = (unsigned)(blocks > 16384 ? 16384 : blocks);
+            if (d == t->num_lods)
+                hipLaunchKernelGGL(k_minmax_leaf, dim3(grid), dim3(256), 0, t->ctx->stream, (const uint8_t*)t->d_height, t->height.w0, rx0, ry0, n, leaf,
+                                   t->d_minmax + base, out + base);
+            else
+                hipLaunchKernelGGL(k_minmax_up, dim3(grid), dim3(256), 0, t->ctx->stream,
+                                   (const uchar2*)(t->d_minmax + ((((uint64_t)1 << (2 * (d + 1))) - 1) / 3)), n, t->d_minmax + base, out + base);
+        }
+        continue;
+    }
     for (int d = 0; d <= t->num_lods; d++) {
         a.depth = d;
         const uint64_t n = (uint64_t)1 << (2 * d);
@@ -428,7 +490,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
         (void)hipFree(g.d_rect); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
         (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_bin_entries);
     }
-    (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights);
+    (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights); (void)hipFree(t->d_minmax);
     delete t;
 }
 
