@@ -302,9 +302,7 @@ __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* _
         out_index = ((size_t)lt * VR_OWNER_TILE + row) * VR_OWNER_TILE + col;
         if (px0 >= a.w || py >= a.h) return;
     } else {
-        // Blocks walk the frame from its end: the tile pass has just written the G-buffer front to
-        // back, so the last ~256 MB are still in the Infinity Cache when this kernel starts.
-        const size_t q = (size_t)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;
+        const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
         const size_t p = q * 4;
         if (p >= (size_t)a.w * a.h) return;
         py = (int)(p / (size_t)a.w); px0 = (int)(p - (size_t)py * a.w);
