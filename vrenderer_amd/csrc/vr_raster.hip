@@ -898,8 +898,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
             // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
             // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
+            // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
+            // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-#define ST4(ptr, a_, b_, c_, d_) do { u4 v_ = { (a_), (b_), (c_), (d_) }; __builtin_nontemporal_store(v_, reinterpret_cast<u4*>(ptr)); } while (0)
+#define ST4(ptr, a_, b_, c_, d_) do { u4 v_ = { (a_), (b_), (c_), (d_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u4*>(ptr)); \
+                                      else *reinterpret_cast<u4*>(ptr) = v_; } while (0)
             ST4(g_depth + pix, __float_as_uint(dep[0]), __float_as_uint(dep[1]), __float_as_uint(dep[2]), __float_as_uint(dep[3]));
             if (!a.depth_only) {
                 uint32_t sp[4];
