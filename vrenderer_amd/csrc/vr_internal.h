@@ -142,6 +142,7 @@ struct GeoSet {
     uint32_t* d_tile_count = nullptr;    // per raster tile
     uint32_t* d_tile_offset = nullptr;
     uint32_t* d_tile_cursor = nullptr;
+    int32_t* d_tile_order = nullptr;     // launch order of the tile pass: this frame's tiles by falling bin length
     uint32_t* d_bin_entries = nullptr;
     int scratch_tiles = 0;
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;

@@ -432,11 +432,31 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 // ---------------------------------------------------------------------------------------
 // k_scan: exclusive prefix sum of the per-tile counts (one workgroup)
 // ---------------------------------------------------------------------------------------
+// It also orders the tiles the tile pass will launch over (all of them, or this rank's `cand` list) by falling bin
+// length (buckets of powers of two; empty bins - the sky - last): workgroups are handed out in launch order, so the
+// expensive tiles start first and the cheap ones fill the tail of the launch (measured: -2.5 % on the 8K tile pass).
 __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity)
+                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity,
+                                                const int32_t* __restrict__ cand, int n_cand, int32_t* __restrict__ order)
 {
     __shared__ uint32_t partial[1024];
+    __shared__ uint32_t hist[33], start[33];
     const int tid = threadIdx.x;
+    if (tid < 33) hist[tid] = 0u;
+    __syncthreads();
+    for (int c = tid; c < n_cand; c += 1024) {
+        const uint32_t cnt = tile_count[cand ? cand[c] : c];
+        atomicAdd(&hist[cnt ? __clz((int)cnt) : 32], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (int k = 0; k < 33; k++) { start[k] = run; run += hist[k]; } }
+    __syncthreads();
+    for (int c = tid; c < n_cand; c += 1024) {
+        const int tile = cand ? cand[c] : c;
+        const uint32_t cnt = tile_count[tile];
+        order[atomicAdd(&start[cnt ? __clz((int)cnt) : 32], 1u)] = tile;
+    }
+    __syncthreads();                                      // every count has been read; they are consumed (zeroed) below
     const int per = (n_tiles + 1023) / 1024;
     const int b = tid * per, e = min(b + per, n_tiles);
     uint32_t s = 0;
@@ -996,11 +1016,12 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     if (n_tiles > g.scratch_tiles) {
         VR_HIP(hipStreamSynchronize(gs));
         VR_HIP(hipStreamSynchronize(s));
-        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor);
-        g.d_tile_count = g.d_tile_offset = g.d_tile_cursor = nullptr; g.scratch_tiles = 0;
+        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order);
+        g.d_tile_count = g.d_tile_offset = g.d_tile_cursor = nullptr; g.d_tile_order = nullptr; g.scratch_tiles = 0;
         VR_HIP(hipMalloc(&g.d_tile_count, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&g.d_tile_offset, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&g.d_tile_cursor, sizeof(uint32_t) * n_tiles));
+        VR_HIP(hipMalloc(&g.d_tile_order, sizeof(int32_t) * n_tiles));
         VR_HIP(hipMemsetAsync(g.d_tile_count, 0, sizeof(uint32_t) * n_tiles, gs));   // k_scan re-zeroes it every frame
         VR_HIP(hipMemsetAsync(g.d_tile_cursor, 0, sizeof(uint32_t) * n_tiles, gs));
         VR_HIP(hipMemsetAsync(g.d_tile_offset, 0, sizeof(uint32_t) * n_tiles, gs));
@@ -1019,7 +1040,9 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     { VrKernelScope ks(ctx, VR_K_CLIP, gs);
     hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count); }
     { VrKernelScope ks(ctx, VR_K_SCAN, gs);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity); }
+    const bool whole = a.world <= 1;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity,
+                       whole ? (const int32_t*)nullptr : (const int32_t*)ctx->d_raster_tiles, whole ? n_tiles : ctx->num_raster_tiles, g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
@@ -1090,7 +1113,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     t->raster_begin_recorded = true;
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER);
-        const int32_t* tiles = whole ? (const int32_t*)nullptr : ctx->d_raster_tiles;
+        const int32_t* tiles = g.d_tile_order;            // this frame's tiles, longest bins first (k_scan)
         auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32> : k_raster<false, 32>)
                                       : (a.wireframe ? k_raster<true, 64> : k_raster<false, 64>);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,

@@ -488,7 +488,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
         (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
         (void)hipFree(g.d_rect); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
-        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_bin_entries);
+        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
     }
     (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights); (void)hipFree(t->d_minmax);
     delete t;
