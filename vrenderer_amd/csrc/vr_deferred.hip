@@ -405,7 +405,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
     }
     const size_t npx = (size_t)gb->w * gb->h;
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
-    VrKernelScope ks(ctx, VR_K_DEFERRED);
+    VrKernelScope ks(ctx, VR_K_DEFERRED, ctx->stream, true);
     if (packed) {
         int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
         if (rc) return rc;
@@ -415,7 +415,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (ctx->num_owned > 0) {
             auto kern = shadow ? k_deferred<true, true, true> : (extra ? k_deferred<true, true> : k_deferred<true, false>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)ctx->num_owned * 16), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+            VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)ctx->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles, sh);
         }
     } else {
@@ -423,10 +423,10 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         if (gb->w % 4 == 0) {
             const size_t quads = npx / 4;
             auto kern = shadow ? k_deferred<false, true, true> : (extra ? k_deferred<false, true> : k_deferred<false, false>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+            VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh);
         } else {
-            hipLaunchKernelGGL(k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a, gb->depth, gb->diffuse,
+            VR_LAUNCH_TIMED(ks, k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, sh, shadow ? 1 : 0);
         }
     }

@@ -100,15 +100,16 @@ static hipEvent_t take_event(vr_context* c)
     return e;
 }
 VrKernelScope::VrKernelScope(vr_context* ctx, int id) : VrKernelScope(ctx, id, ctx->stream) {}
-VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream) : c(ctx), st(stream)
+VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream) : VrKernelScope(ctx, id, stream, false) {}
+VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream, bool attach_) : c(ctx), st(stream), attach(attach_)
 {
     if (!c->timing) return;
-    hipEvent_t e0 = take_event(c); e1 = take_event(c);
-    if (!e0 || !e1) { e1 = nullptr; return; }
-    (void)hipEventRecord(e0, st);
+    e0 = take_event(c); e1 = take_event(c);
+    if (!e0 || !e1) { e0 = e1 = nullptr; return; }
+    if (!attach) (void)hipEventRecord(e0, st);
     c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
 }
-VrKernelScope::~VrKernelScope() { if (e1) (void)hipEventRecord(e1, st); }
+VrKernelScope::~VrKernelScope() { if (e1 && !attach) (void)hipEventRecord(e1, st); }
 
 static void timing_reset(vr_context* c)
 {

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -108,11 +109,19 @@ struct vr_context {
 
 // Records a begin/end event pair around one kernel launch when timing is enabled.
 struct VrKernelScope {
-    vr_context* c; hipEvent_t e1 = nullptr; hipStream_t st = nullptr;
+    vr_context* c; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; bool attach = false;
     VrKernelScope(vr_context* ctx, int id);                       // on the context's stream
     VrKernelScope(vr_context* ctx, int id, hipStream_t stream);   // on another stream of the same device
+    // attach = true: the events are not recorded as separate stream operations; the launch passes them to
+    // hipExtLaunchKernelGGL (VR_LAUNCH_TIMED), which stamps them from the dispatch itself - no extra packets between
+    // two dependent kernels on the stream
+    VrKernelScope(vr_context* ctx, int id, hipStream_t stream, bool attach);
     ~VrKernelScope();
 };
+// launch under a scope created with attach = true
+#define VR_LAUNCH_TIMED(scope, kernel, grid, block, stream, ...) do { \
+        if ((scope).e0 && (scope).e1) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (scope).e0, (scope).e1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); } while (0)
 
 struct vr_gbuffer {
     vr_context* ctx;

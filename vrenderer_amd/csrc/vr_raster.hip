@@ -1112,11 +1112,11 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     VR_HIP(hipEventRecord(t->ev_raster_begin, s));
     t->raster_begin_recorded = true;
     if (grid > 0) {
-        VrKernelScope ks(ctx, VR_K_RASTER);
+        VrKernelScope ks(ctx, VR_K_RASTER, s, true);
         const int32_t* tiles = g.d_tile_order;            // this frame's tiles, longest bins first (k_scan)
         auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32> : k_raster<false, 32>)
                                       : (a.wireframe ? k_raster<true, 64> : k_raster<false, 64>);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
+        VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
