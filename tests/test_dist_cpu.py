@@ -1,6 +1,7 @@
 """N > 1 on CPU: two gloo ranks each render + light only their interleaved screen tiles (with the
 oracle standing in for the device kernels), pack them tile-major, all-gather with equal send counts
-and de-tile — the assembled frame must equal the unsplit frame byte for byte (SURVEY §4 iv, §8e)."""
+and de-tile — the assembled frame must equal the unsplit frame byte for byte (SURVEY §4 iv, §8e); the same for the
+tone-mapped exchange (histogram all-reduce + RGB8 tiles)."""
 import os
 import socket
 import sys
@@ -43,6 +44,21 @@ def _worker(rank, world, port, w, h, out_dir):
     dist.all_gather_into_tensor(gathered, packed)              # equal send counts on every rank
     frame = pt.detile(gathered.numpy().view(np.uint16).reshape((-1,) + packed_np.shape[1:]), w, h, world)
     np.save(os.path.join(out_dir, f"frame_{rank}.npy"), frame)
+    # the tone-mapped exchange (row f3): own pixels -> histogram, all-reduce of the 256 bins, same exposure everywhere,
+    # RGB8 tiles gathered, alpha restored
+    tmp = vr.default_tonemap_params()
+    tm = po.ToneMapper()
+    tm.AdvanceFrame(1.0 / 60.0)
+    tm.AddFrameToHistogram(tmp, hdr, vr.Partition(rank, world))
+    hist = torch.from_numpy(tm.hist.astype(np.int64))
+    dist.all_reduce(hist)
+    tm.hist[:] = hist.numpy().astype(np.uint32)
+    tm.ComputeExposure(tmp)
+    ldr = tm.Render(tmp, hdr)                                   # only this rank's tiles of it are meaningful
+    packed_ldr = torch.from_numpy(pt.pack(ldr, rank, world).reshape(-1))
+    gathered_ldr = torch.empty(world * packed_ldr.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered_ldr, packed_ldr)
+    np.save(os.path.join(out_dir, f"ldr_{rank}.npy"), pt.detile(gathered_ldr.numpy().reshape((-1,) + pt.packed_shape(w, h, world)[1:]), w, h, world, alpha=255))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +87,11 @@ def test_two_rank_tile_split_allgather_equals_unsplit(oracle, tmp_path):
     gb = oracle.GBufferHost(w, h)
     t.render(v, gb, vr.default_render_params(400.0))
     ref = oracle.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)
+    tm = oracle.ToneMapper()
+    tm.AdvanceFrame(1.0 / 60.0)
+    ref_ldr = tm.SimpleRender(vr.default_tonemap_params(), ref)
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"frame_{r}.npy"))
         assert np.array_equal(got, ref), f"rank {r}: assembled frame differs from the unsplit frame"
+        got_ldr = np.load(os.path.join(str(tmp_path), f"ldr_{r}.npy"))
+        assert np.array_equal(got_ldr, ref_ldr), f"rank {r}: assembled tone-mapped frame differs from the unsplit one"

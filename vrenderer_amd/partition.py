@@ -6,7 +6,7 @@ reason about the same layout):
 
   * owner tiles are 128x128 pixels, owner(tx, ty) = (tx + ty) mod world_size;
   * a rank's packed buffer is [local tile][128 rows][128 px] RGB16F (alpha is always 0 and is
-    not exchanged), local tiles in
+    not exchanged) or, tone-mapped, RGB8 (alpha always 255), local tiles in
     row-major order of the rank's owned tiles, padded to `max_owned` tiles so that every
     rank's all-gather send count is equal;
   * after the all-gather, tile t of the frame lives at slot owner*max_owned + local.
@@ -59,12 +59,14 @@ def pack(frame, rank, world):
     return out
 
 
-def detile(gathered, width, height, world):
-    """gathered: (world * max_owned, 128, 128, 3) -> (H, W, 4) frame (alpha 0)."""
+def detile(gathered, width, height, world, alpha=0):
+    """gathered: (world * max_owned, 128, 128, 3) -> (H, W, 4) frame; the alpha that was not exchanged is filled in
+    (0 for HdrColor, 255 for the tone-mapped LdrColor)."""
     tx, ty = owner_grid(width, height)
     slot = tile_slots(width, height, world)
     g = gathered.reshape(-1, TILE, TILE, 3)
     out = np.zeros((height, width, 4), gathered.dtype)
+    out[..., 3] = alpha
     for t in range(tx * ty):
         y0, x0 = (t // tx) * TILE, (t % tx) * TILE
         hh, ww = min(TILE, height - y0), min(TILE, width - x0)
