@@ -172,13 +172,20 @@ def main():
         packed = [torch.empty(rows * vr.VR_OWNER_TILE * 4, dtype=torch.float16, device="cuda") for _ in range(nbuf)]
         hdr_bufs = [vr.HdrImage(ctx, vr.VR_OWNER_TILE, rows, external_ptr=t.data_ptr()) for t in packed]
         main_stream = torch.cuda.current_stream()
+        ctx_post = ctx
         if nbuf > 1:
             comm_stream = torch.cuda.Stream()
             ctx_comm = vr.Context(local_rank)
             ctx_comm.set_stream(comm_stream.cuda_stream)
+            # the de-tile of frame i has no part in the exchange itself: on a third stream it runs under frame i+1's all-gather
+            post_stream = torch.cuda.Stream()
+            ctx_post = vr.Context(local_rank)
+            ctx_post.set_stream(post_stream.cuda_stream)
         else:
-            comm_stream = main_stream
+            comm_stream = post_stream = main_stream
         partition_prepare(ctx_comm, W, H, part)
+        if ctx_post is not ctx_comm:
+            partition_prepare(ctx_post, W, H, part)
         ldr = args.exchange == "ldr"
         if ldr:
             # f3: the frame leaves each rank tone-mapped (Renderer.cpp:430-431); all of it runs on the exchange stream
@@ -194,11 +201,13 @@ def main():
             packed_ldr = [torch.empty(ldr_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
             ldr_bufs = [vr.LdrImage(ctx_comm, W, H, external_ptr=t.data_ptr(), capacity_bytes=ldr_bytes) for t in packed_ldr]
             gathered_ldr = [torch.empty(world * ldr_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-            frame = vr.LdrImage(ctx_comm, W, H)
+            frame = vr.LdrImage(ctx_post, W, H)
         else:
-            frame = vr.HdrImage(ctx_comm, W, H)
+            frame = vr.HdrImage(ctx_post, W, H)
         render_done = [torch.cuda.Event() for _ in range(nbuf)]
-        comm_done = [torch.cuda.Event() for _ in range(nbuf)]
+        comm_done = [torch.cuda.Event() for _ in range(nbuf)]       # the send buffers of slot b are free again
+        gather_done = [torch.cuda.Event() for _ in range(nbuf)]     # gathered[b] is complete
+        post_done = [torch.cuda.Event() for _ in range(nbuf)]       # gathered[b] has been consumed by the de-tile
         from vrenderer_amd import partition as pt
         tx_ = pt.owner_grid(W, H)[0]
         owned_px = sum(min(128, W - (t % tx_) * 128) * min(128, H - (t // tx_) * 128) for t in pt.owned_tiles(W, H, rank, world))
@@ -250,6 +259,7 @@ def main():
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
+            comm_stream.wait_event(post_done[b])                           # gathered[b] is free (no-op before first use)
             if ldr:
                 tm.ResetHistogram()
                 tm.AddFrameToHistogram(tmp, hdr_bufs[b], W, H, part)       # this rank's pixels
@@ -257,11 +267,17 @@ def main():
                 tm.ComputeExposure(tmp)
                 tm.Render(tmp, hdr_bufs[b], ldr_bufs[b], W, H, part)       # packed RGB16F tiles -> packed RGB8 tiles
                 allgather(gathered_ldr[b], packed_ldr[b])
-                frame_detile_ldr(ctx_comm, gathered_ldr[b].data_ptr(), world, W, H, frame)
             else:
                 allgather(gathered[b].view(torch.uint8), packed[b][:half_elems].view(torch.uint8))
-                frame_detile(ctx_comm, gathered[b].data_ptr(), world, frame)
+            gather_done[b].record(comm_stream)
             comm_done[b].record(comm_stream)
+        with torch.cuda.stream(post_stream):
+            post_stream.wait_event(gather_done[b])
+            if ldr:
+                frame_detile_ldr(ctx_post, gathered_ldr[b].data_ptr(), world, W, H, frame)
+            else:
+                frame_detile(ctx_post, gathered[b].data_ptr(), world, frame)
+            post_done[b].record(post_stream)
 
     def sync():
         if use_dist:
@@ -275,8 +291,9 @@ def main():
         step(i)
     sync()
     ctx.timing_enable(True)          # HIP events around every kernel, on the stream they are launched on
-    if ctx_comm is not ctx:
-        ctx_comm.timing_enable(True)
+    side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx)) if c is not ctx]
+    for c in side_ctxs:
+        c.timing_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -284,9 +301,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timings = ctx.timing_collect()
     ctx.timing_enable(False)
-    if ctx_comm is not ctx:
-        timings.update(ctx_comm.timing_collect())
-        ctx_comm.timing_enable(False)
+    for c in side_ctxs:
+        timings.update(c.timing_collect())
+        c.timing_enable(False)
     n_nodes = tp.num_chunks()
 
     verified = None
@@ -364,7 +381,8 @@ def main():
                                        "+all-gather of RGB16F tiles+detile") if use_dist else ""),
                        "resolution": [W, H], "heightmap": size, "nodes_last_frame": n_nodes,
                        "parallelism": f"screen tiles {vr.VR_OWNER_TILE}x{vr.VR_OWNER_TILE}, owner=(tx+ty)%{world}"
-                                      + (", all-gather of frame i overlapped with rendering of frame i+1" if use_dist and not args.no_overlap else "")},
+                                      + (", tone map + all-gather of frame i under the rendering of frame i+1, de-tile of frame i under the all-gather of frame i+1"
+                                         if use_dist and not args.no_overlap else "")},
             # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
             "roofline": roof_deferred,
             "roofline_gbuffer_fill": roof_raster,
