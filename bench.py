@@ -86,7 +86,7 @@ def ot_num_lods(size):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=120, help="timed frames; the default is one whole lap of the 120-frame flythrough")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
