@@ -690,9 +690,13 @@ def test_two_rank_frame_split_rehearsal_on_one_gpu():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--width", "1920", "--height", "1080", "--rehearse-on-one-gpu", "--verify", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
