@@ -50,7 +50,8 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
             while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
             tab[b] = (uint8_t)lo;
         }
-        VR_HIP(hipMalloc(&c->d_enc_tab, kEncTabSize));
+        VR_HIP(hipMalloc(&c->d_enc_tab, (kEncTabSize + 3) / 4 * 4));          // read as dwords by the kernels
+        VR_HIP(hipMemset(c->d_enc_tab, 0, (kEncTabSize + 3) / 4 * 4));
         VR_HIP(hipMemcpy(c->d_enc_tab, tab, kEncTabSize, hipMemcpyHostToDevice));
     }
     *out = c;

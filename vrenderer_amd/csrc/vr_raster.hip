@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const)
 {
     __shared__ unsigned long long vis[TILE * TILE];
-    __shared__ uint8_t enc[kEncTabSize + 3];
+    __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float lut[256];
     __shared__ float thr[256];
     __shared__ float r8[256];
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
-    for (int i = tid; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
+    for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;

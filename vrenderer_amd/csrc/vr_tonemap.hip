@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256) void k_tonemap(TmArgs a, const void* __restric
                                                   const float* __restrict__ thr_g, const uint8_t* __restrict__ enc_g)
 {
     __shared__ float thr[256];
-    __shared__ uint8_t enc[kEncTabSize + 3];
+    __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     thr[threadIdx.x] = thr_g[threadIdx.x];
-    for (int i = threadIdx.x; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
+    for (int i = threadIdx.x; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     __syncthreads();
     const QuadPos q = quad_pos<PACKED>(a, owned_tiles, blockIdx.x, (int)threadIdx.x);
     if (q.valid == 0) return;
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(256) void k_tonemap_scalar(TmArgs a, const uint2* _
                                                          const uint8_t* __restrict__ enc_g)
 {
     __shared__ float thr[256];
-    __shared__ uint8_t enc[kEncTabSize + 3];
+    __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     thr[threadIdx.x] = thr_g[threadIdx.x];
-    for (int i = threadIdx.x; i < kEncTabSize; i += 256) enc[i] = enc_g[i];
+    for (int i = threadIdx.x; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     __syncthreads();
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)a.w * a.h) return;
