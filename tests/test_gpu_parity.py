@@ -1081,3 +1081,34 @@ def test_large_heightmap_8192(oracle, gpu_ctx):
         _assert_gbuffer_equal(gb_o, planes, "8192 close camera")
     finally:
         tp.close(); ot.close()
+
+
+def test_random_texture_fuzz_bit_exact(oracle, gpu_ctx):
+    """White-noise heightmap and albedo (every texel differs from its neighbours: steep slopes, every LOD level and
+    clamp of the filter gets exercised), non-square textures of different sizes, 16 random views: bit-exact."""
+    rng = np.random.default_rng(31337)
+    for (hw, hh, aw, ah) in ((256, 256, 256, 256), (192, 320, 512, 128)):
+        h = rng.integers(0, 256, size=(hh, hw), dtype=np.uint8)
+        a = rng.integers(0, 256, size=(ah, aw, 4), dtype=np.uint8)
+        p = params(256)
+        ot = oracle.OracleTerrain(p, h, a)
+        tp = vr.TerrainPass(gpu_ctx, p).Init(h, a)
+        sc = dict(ot=ot, tp=tp, size=256, h=np.zeros((256, 256), np.uint8))
+        try:
+            for l in range(ot.height_levels()):
+                assert np.array_equal(tp.download_mip("height", l), ot.height_mip(l))
+            for l in range(ot.albedo_levels()):
+                assert np.array_equal(tp.download_mip("albedo", l), ot.albedo_mip(l))
+            for it, eye, tgt, up, fov, w, hgt in _fuzz_views(rng, 8, sc["h"], 256):
+                v = vr.make_view(eye, tgt, w, hgt, vfov_deg=fov, up=up)
+                rp = vr.default_render_params(400.0, assume_cleared=1)
+                gb_o = oracle.GBufferHost(w, hgt)
+                n_o = ot.render(v, gb_o, rp, None)
+                rt = vr.RenderTargets(gpu_ctx).Init(w, hgt)
+                tp.Render(v, v, rt, rp, None)
+                planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+                assert tp.num_chunks() == n_o
+                rt.close()
+                _assert_gbuffer_equal(gb_o, planes, f"noise textures {hw}x{hh}/{aw}x{ah}, view {it}: eye {eye} target {tgt} fov {fov}")
+        finally:
+            tp.close(); ot.close()
