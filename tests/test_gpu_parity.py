@@ -1112,3 +1112,50 @@ def test_random_texture_fuzz_bit_exact(oracle, gpu_ctx):
                 _assert_gbuffer_equal(gb_o, planes, f"noise textures {hw}x{hh}/{aw}x{ah}, view {it}: eye {eye} target {tgt} fov {fov}")
         finally:
             tp.close(); ot.close()
+
+
+def test_api_sequence_fuzz(scene256, oracle, gpu_ctx):
+    """A random sequence of the frame-loop calls (Render, Prepare for the same or another view, lock-view renders, a rank's
+    partition, SetHeight toggles, stand-alone NodeSelect): every frame must still equal the oracle's. Exercises the
+    double-buffered geometry sets, the prepared-geometry matching and the cross-stream dependencies."""
+    rng = np.random.default_rng(424242)
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 320, 180
+    views = [vr.make_view(*scaled_camera(c, 256), w, h) for c in CAMERAS]
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    heights = False
+    can_lock = False
+    try:
+        for step in range(70):
+            op = rng.choice(["render", "render", "prepare_render", "prepare_other", "lock", "part", "height", "select"])
+            v = views[int(rng.integers(len(views)))]
+            if op == "height":
+                heights = not heights
+                ot.set_height(heights); tp.SetHeight(heights)
+                can_lock = False
+                continue
+            if op == "select":
+                n_o, ids_o, inst_o = ot.select(v, 400.0)
+                n_g, ids_g, inst_g = tp.NodeSelect(v, 400.0)
+                assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), (step, op)
+                can_lock = False                         # a stand-alone NodeSelect is not part of the reference's Render state
+                continue
+            part = vr.Partition(int(rng.integers(0, 3)), 3) if op == "part" else None
+            lock = op == "lock" and can_lock
+            rp = vr.default_render_params(400.0, assume_cleared=1, lock_view=int(lock))
+            if op == "prepare_render":
+                tp.Prepare(v, rt, rp, part)
+            elif op == "prepare_other":
+                tp.Prepare(views[int(rng.integers(len(views)))], rt, rp, part)
+            gb_o = oracle.GBufferHost(w, h)
+            n_o = ot.render(v, gb_o, rp, part)
+            if part is not None:
+                rt.Clear()                               # a rank leaves the tiles it does not own alone
+            tp.Render(v, v, rt, rp, part)
+            planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+            assert tp.num_chunks() == n_o, (step, op)
+            _assert_gbuffer_equal(gb_o, planes, f"step {step} ({op}, heights {heights}, lock {lock})")
+            can_lock = True
+    finally:
+        ot.set_height(False); tp.SetHeight(False)
+        rt.close()
