@@ -1159,3 +1159,39 @@ def test_api_sequence_fuzz(scene256, oracle, gpu_ctx):
     finally:
         ot.set_height(False); tp.SetHeight(False)
         rt.close()
+
+
+def test_shadow_fuzz(scene256, oracle, gpu_ctx):
+    """Random sun directions, cameras, map resolutions and biases: the light view (host code vs restatement), the terrain
+    shadow map (bit-exact) and the shadowed lighting pass (no flipped PCF comparison: max error at rounding level)."""
+    import ctypes as C
+    rng = np.random.default_rng(777)
+    w, h = 320, 180
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    for it in range(8):
+        cam = vr.make_view(*scaled_camera(CAMERAS[int(rng.integers(len(CAMERAS)))], 256), w, h)
+        d = rng.normal(size=3); d[1] = -abs(d[1]) - 0.15                      # the sun is above the horizon
+        sun = vr.directional_light(tuple(d), 1.0, 0.53)
+        sun.out_of_bounds_shadow = float(rng.choice([0.0, 1.0]))
+        res = int(rng.choice([256, 384, 512]))
+        bias = float(rng.choice([0.0, 0.001, 0.004]))
+        sm = vr.CascadedShadowMap(gpu_ctx, vr.default_shadow_params(256.0, resolution=res, depth_bias=bias,
+                                                                    max_shadow_distance=float(rng.choice([64.0, 256.0]))))
+        lv = sm.SetupForPlanarViewStable(sun, cam)
+        assert bytes(lv) == bytes(oracle.shadow_view(sun, cam, sm.params)), it
+        sm.Clear(); sm.RenderTerrain(scene256["tp"])
+        gb_l = oracle.GBufferHost(res, res)
+        scene256["ot"].render(lv, gb_l, vr.default_render_params(400.0, depth_only=1))
+        assert np.array_equal(sm.download_depth().view(np.uint32), gb_l.depth.view(np.uint32)), f"case {it}: shadow map"
+        scene256["tp"].Render(cam, cam, rt, vr.default_render_params(400.0, assume_cleared=1))
+        dl.Render(cam, rt, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, hdr, shadow_map=sm)
+        gb = oracle.GBufferHost(w, h)
+        for name, arr in (("depth", gb.depth), ("diffuse", gb.diffuse), ("specular", gb.specular), ("normals", gb.normals), ("emissive", gb.emissive)):
+            arr[...] = rt.download(name)
+        want = oracle.deferred(cam, gb, [sun], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv, gb_l.depth, 0, bias))
+        err = np.abs(oracle.half_to_float(hdr.download()).astype(np.float64)[..., :3] - want[..., :3])
+        assert err.max() < 2e-3 and np.sqrt((err ** 2).mean()) <= 1e-4, (it, err.max())
+        sm.close()
+    hdr.close(); rt.close()
