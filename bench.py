@@ -366,7 +366,9 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"), "avg_us": round(avg_s * 1e6, 2),
                     "bytes_per_launch": bytes_per_px * px,
-                    "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"}
+                    "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"
+                            + ("; a kernel that only moves the same bytes reaches 5.6-5.9 TB/s on this part (profiles/r01_stream_layout_ceiling.txt)"
+                               if name == "k_deferred" else "; the tile pass is instruction-issue bound (exact fp32 filtering without texture units), see DESIGN.md 4")}
 
         roof_deferred = roof("k_deferred", DEFERRED_BYTES_PER_PX, owned_px)
         roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
