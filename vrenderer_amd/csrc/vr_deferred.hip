@@ -407,16 +407,17 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
     VrKernelScope ks(ctx, VR_K_DEFERRED, ctx->stream, true);
     if (packed) {
-        int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
+        const PartTables* pt = nullptr;
+        int rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt);
         if (rc) return rc;
-        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes,
+        VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes,
                    "hdr_out is smaller than vr_partition_packed_bytes()");
         VR_REQUIRE(gb->w % 4 == 0, "partitioned frames need a width that is a multiple of 4");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
-        if (ctx->num_owned > 0) {
+        if (pt->num_owned > 0) {
             auto kern = shadow ? k_deferred<true, true, true> : (extra ? k_deferred<true, true> : k_deferred<true, false>);
-            VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)ctx->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, ctx->d_owned_tiles, sh);
+            VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)pt->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, pt->d_owned_tiles, sh);
         }
     } else {
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
@@ -646,15 +647,16 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     VR_REQUIRE(gb->w % 4 == 0, "the tiled pass needs a frame width that is a multiple of 4");
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
     if (packed) {
-        int rc = vr_ensure_partition(ctx, gb->w, gb->h, part);
+        const PartTables* pt = nullptr;
+        int rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt);
         if (rc) return rc;
-        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
+        VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         const int sub = VR_OWNER_TILE / kLightTile;
-        if (ctx->num_owned > 0)
-            hipLaunchKernelGGL(k_deferred_tiled<true>, dim3((unsigned)ctx->num_owned * sub * sub), dim3(256), 0, ctx->stream, a, ctx->d_lights,
+        if (pt->num_owned > 0)
+            hipLaunchKernelGGL(k_deferred_tiled<true>, dim3((unsigned)pt->num_owned * sub * sub), dim3(256), 0, ctx->stream, a, ctx->d_lights,
                                num_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
-                               ctx->d_srgb_lut, ctx->d_owned_tiles, ctx->d_flags);
+                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_flags);
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         const int tx = (gb->w + kLightTile - 1) / kLightTile, ty = (gb->h + kLightTile - 1) / kLightTile;
@@ -686,15 +688,15 @@ __global__ __launch_bounds__(256) void k_detile(const uint32_t* __restrict__ gat
 extern "C" VR_API int vr_frame_detile(vr_context* ctx, const void* gathered, int32_t world, vr_image* frame)
 {
     VR_REQUIRE(ctx && gathered && frame, "NULL argument");
-    VR_REQUIRE(ctx->part_world == world && ctx->part_w == frame->w && ctx->part_h == frame->h,
-               "vr_frame_detile must follow vr_deferred_light with the same partition and frame size");
-    VR_REQUIRE(frame->w % 2 == 0, "frame width must be even");
+    VR_REQUIRE(frame->w % 2 == 0 && world >= 1, "frame width must be even");
     VR_HIP(hipSetDevice(ctx->device));
+    const PartTables* pt = nullptr;
+    { int rc = vr_partition_slot_tables(ctx, frame->w, frame->h, world, &pt); if (rc) return rc; }
     const size_t pairs = (size_t)frame->w * frame->h / 2;
     const int tiles_x = (frame->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
     VrKernelScope ks(ctx, VR_K_DETILE);
     hipLaunchKernelGGL(k_detile, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)gathered,
-                       (uint4*)frame->data, frame->w, frame->h, tiles_x, ctx->d_tile_slot);
+                       (uint4*)frame->data, frame->w, frame->h, tiles_x, pt->d_tile_slot);
     VR_HIP(hipGetLastError());
     return VR_OK;
 }

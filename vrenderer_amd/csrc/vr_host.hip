@@ -64,7 +64,10 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); (void)hipFree(c->d_enc_tab);
     (void)hipFree(c->d_lights); (void)hipFree(c->d_flags);
-    (void)hipFree(c->d_owned_tiles); (void)hipFree(c->d_tile_slot); (void)hipFree(c->d_raster_tiles);
+    for (PartTables* pt : c->part_tables) {
+        (void)hipFree(pt->d_owned_tiles); (void)hipFree(pt->d_tile_slot); (void)hipFree(pt->d_raster_tiles);
+        delete pt;
+    }
     timing_reset(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -102,15 +105,29 @@ static hipEvent_t take_event(vr_context* c)
 }
 VrKernelScope::VrKernelScope(vr_context* ctx, int id) : VrKernelScope(ctx, id, ctx->stream) {}
 VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream) : VrKernelScope(ctx, id, stream, false) {}
-VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream, bool attach_) : c(ctx), st(stream), attach(attach_)
+VrKernelScope::VrKernelScope(vr_context* ctx, int id_, hipStream_t stream, bool attach_) : c(ctx), st(stream), attach(attach_), id(id_)
 {
     if (!c->timing) return;
     e0 = take_event(c); e1 = take_event(c);
-    if (!e0 || !e1) { e0 = e1 = nullptr; return; }
-    if (!attach) (void)hipEventRecord(e0, st);
-    c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
+    if (!e0 || !e1) {
+        if (e0) c->ev_pool.push_back(e0);
+        if (e1) c->ev_pool.push_back(e1);
+        e0 = e1 = nullptr; return;
+    }
+    if (!attach) { (void)hipEventRecord(e0, st); commit(); }
 }
-VrKernelScope::~VrKernelScope() { if (e1 && !attach) (void)hipEventRecord(e1, st); }
+void VrKernelScope::commit()
+{
+    if (committed || !e0 || !e1) return;
+    c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
+    committed = true;
+}
+VrKernelScope::~VrKernelScope()
+{
+    if (!e0 || !e1) return;
+    if (!attach) (void)hipEventRecord(e1, st);
+    else if (!committed) { c->ev_pool.push_back(e0); c->ev_pool.push_back(e1); }
+}
 
 static void timing_reset(vr_context* c)
 {
@@ -123,6 +140,8 @@ extern "C" VR_API int vr_timing_enable(vr_context* c, int enable)
     VR_REQUIRE(c != nullptr, "ctx is NULL");
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
+    // pairs recorded on a terrain's geometry stream may still be pending: wait for each before its events are recycled
+    for (hipEvent_t e : c->ev_end) (void)hipEventSynchronize(e);
     timing_reset(c);
     c->timing = enable != 0;
     return VR_OK;
@@ -133,14 +152,16 @@ extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT],
     VR_HIP(hipSetDevice(c->device));
     VR_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < VR_K_COUNT; i++) { ms_sum[i] = 0.0f; launches[i] = 0; }
+    int rc = VR_OK;
     for (size_t i = 0; i < c->ev_id.size(); i++) {
         float ms = 0.0f;
-        VR_HIP(hipEventSynchronize(c->ev_end[i]));      // may have been recorded on a terrain's geometry stream
-        VR_HIP(hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+        hipError_t e = hipEventSynchronize(c->ev_end[i]);      // may have been recorded on a terrain's geometry stream
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]);
+        if (e != hipSuccess) { vr_set_error("vr_timing_collect: %s", hipGetErrorString(e)); rc = VR_ERR_HIP; continue; }
         ms_sum[c->ev_id[i]] += ms; launches[c->ev_id[i]]++;
     }
-    timing_reset(c);
-    return VR_OK;
+    timing_reset(c);                                     // also on the error path: a bad pair must not persist
+    return rc;
 }
 extern "C" VR_API const char* vr_kernel_name(int id)
 {
@@ -498,14 +519,24 @@ extern "C" VR_API size_t vr_partition_packed_bytes(int32_t w, int32_t h, int32_t
 extern "C" VR_API int vr_partition_prepare(vr_context* ctx, int32_t w, int32_t h, const vr_partition* part)
 {
     VR_REQUIRE(ctx && w > 0 && h > 0, "bad arguments");
-    return vr_ensure_partition(ctx, w, h, part);
+    const PartTables* pt;
+    return vr_partition_tables(ctx, w, h, part, &pt);
 }
 
-int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part)
+int vr_partition_slot_tables(vr_context* ctx, int w, int h, int world, const PartTables** out)
+{
+    for (const PartTables* pt : ctx->part_tables)
+        if (pt->w == w && pt->h == h && pt->world == world) { *out = pt; return VR_OK; }
+    const vr_partition p0 = { 0, world };
+    return vr_partition_tables(ctx, w, h, &p0, out);
+}
+
+int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out)
 {
     int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
     VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
-    if (ctx->part_w == w && ctx->part_h == h && ctx->part_rank == rank && ctx->part_world == world) return VR_OK;
+    for (const PartTables* pt : ctx->part_tables)
+        if (pt->w == w && pt->h == h && pt->rank == rank && pt->world == world) { *out = pt; return VR_OK; }
     VR_HIP(hipSetDevice(ctx->device));
     int tx, ty; owner_grid(w, h, &tx, &ty);
     int max_owned = 0;
@@ -526,17 +557,26 @@ int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part)
             }
         }
     }
-    // The partition tables may still be in use by kernels in flight on the stream.
-    VR_HIP(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_owned_tiles); (void)hipFree(ctx->d_tile_slot); (void)hipFree(ctx->d_raster_tiles);
-    ctx->d_owned_tiles = ctx->d_tile_slot = ctx->d_raster_tiles = nullptr;
-    VR_HIP(hipMalloc(&ctx->d_owned_tiles, sizeof(int32_t) * (owned.size() + 1)));
-    VR_HIP(hipMalloc(&ctx->d_tile_slot, sizeof(int32_t) * slot.size()));
-    VR_HIP(hipMalloc(&ctx->d_raster_tiles, sizeof(int32_t) * (raster.size() + 1)));
-    if (!owned.empty()) VR_HIP(hipMemcpy(ctx->d_owned_tiles, owned.data(), sizeof(int32_t) * owned.size(), hipMemcpyHostToDevice));
-    VR_HIP(hipMemcpy(ctx->d_tile_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice));
-    if (!raster.empty()) VR_HIP(hipMemcpy(ctx->d_raster_tiles, raster.data(), sizeof(int32_t) * raster.size(), hipMemcpyHostToDevice));
-    ctx->num_owned = (int)owned.size(); ctx->max_owned = max_owned; ctx->num_raster_tiles = (int)raster.size();
-    ctx->part_w = w; ctx->part_h = h; ctx->part_rank = rank; ctx->part_world = world;
+    PartTables* pt = new PartTables();
+    pt->w = w; pt->h = h; pt->rank = rank; pt->world = world;
+    auto fail = [&](hipError_t e, const char* what) {
+        vr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, what, hipGetErrorString(e));
+        (void)hipFree(pt->d_owned_tiles); (void)hipFree(pt->d_tile_slot); (void)hipFree(pt->d_raster_tiles);
+        delete pt;
+        return e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&pt->d_owned_tiles, sizeof(int32_t) * (owned.size() + 1))) != hipSuccess) return fail(e, "hipMalloc(owned tiles)");
+    if ((e = hipMalloc(&pt->d_tile_slot, sizeof(int32_t) * slot.size())) != hipSuccess) return fail(e, "hipMalloc(tile slots)");
+    if ((e = hipMalloc(&pt->d_raster_tiles, sizeof(int32_t) * (raster.size() + 1))) != hipSuccess) return fail(e, "hipMalloc(raster tiles)");
+    // blocking copies from pageable memory: the tables are complete before any kernel that names them is queued
+    if (!owned.empty() && (e = hipMemcpy(pt->d_owned_tiles, owned.data(), sizeof(int32_t) * owned.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy(owned tiles)");
+    if ((e = hipMemcpy(pt->d_tile_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(tile slots)");
+    if (!raster.empty() && (e = hipMemcpy(pt->d_raster_tiles, raster.data(), sizeof(int32_t) * raster.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy(raster tiles)");
+    pt->num_owned = (int)owned.size(); pt->max_owned = max_owned; pt->num_raster_tiles = (int)raster.size();
+    ctx->part_tables.push_back(pt);
+    *out = pt;
     return VR_OK;
 }

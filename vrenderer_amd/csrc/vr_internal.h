@@ -82,6 +82,15 @@ static_assert(sizeof(DevVert) == 48, "DevVert layout");
 struct HardTriRec { uint32_t v0, v1, v2, order_key; uint32_t rect_lo, rect_hi, pad0, pad1; };
 static_assert(sizeof(HardTriRec) == 32, "HardTriRec layout");
 
+// Screen-tile partition of a w x h frame for one rank of `world`: built once, immutable afterwards.
+struct PartTables {
+    int w = 0, h = 0, rank = 0, world = 1;
+    int32_t* d_owned_tiles = nullptr;   // owner-tile ids (128x128) owned by this rank
+    int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
+    int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64 or 32x32) inside owned owner tiles
+    int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+};
+
 struct vr_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -90,12 +99,10 @@ struct vr_context {
     float h_srgb_lut[256];
     float h_srgb_thr[256];
     uint8_t* d_enc_tab = nullptr;  // kEncTabSize bytes: sRGB8 code of the smallest float of each bucket
-    // cached partition tables (device), rebuilt when (w,h,rank,world) changes
-    int part_w = 0, part_h = 0, part_rank = -1, part_world = 0;
-    int32_t* d_owned_tiles = nullptr;   // owner-tile ids (128x128) owned by this rank
-    int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
-    int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64) inside owned owner tiles
-    int num_owned = 0, max_owned = 0, num_raster_tiles = 0;
+    // partition tables (device), one set per (w,h,rank,world) seen; they live as long as the context, so a
+    // kernel queued on any stream can never read a freed or foreign table (a frame alternates between the
+    // shadow map's and the main view's geometry every frame)
+    std::vector<PartTables*> part_tables;
     bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
     // light list of vr_deferred_light_tiled
     DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights;
@@ -109,18 +116,21 @@ struct vr_context {
 
 // Records a begin/end event pair around one kernel launch when timing is enabled.
 struct VrKernelScope {
-    vr_context* c; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; bool attach = false;
+    vr_context* c; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; bool attach = false; int id = 0; bool committed = false;
     VrKernelScope(vr_context* ctx, int id);                       // on the context's stream
     VrKernelScope(vr_context* ctx, int id, hipStream_t stream);   // on another stream of the same device
     // attach = true: the events are not recorded as separate stream operations; the launch passes them to
     // hipExtLaunchKernelGGL (VR_LAUNCH_TIMED), which stamps them from the dispatch itself - no extra packets between
     // two dependent kernels on the stream
     VrKernelScope(vr_context* ctx, int id, hipStream_t stream, bool attach);
+    // the pair enters the context's list only once something will stamp it (attach = true: after the launch was issued;
+    // a scope that returns early without launching hands its events back instead of leaving a never-recorded pair)
+    void commit();
     ~VrKernelScope();
 };
 // launch under a scope created with attach = true
 #define VR_LAUNCH_TIMED(scope, kernel, grid, block, stream, ...) do { \
-        if ((scope).e0 && (scope).e1) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (scope).e0, (scope).e1, 0, __VA_ARGS__); \
+        if ((scope).e0 && (scope).e1) { hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (scope).e0, (scope).e1, 0, __VA_ARGS__); (scope).commit(); } \
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); } while (0)
 
 struct vr_gbuffer {
@@ -190,7 +200,10 @@ struct vr_terrain {
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
                           DevTex* out, uint8_t** out_mem);
 int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream);
-int vr_ensure_partition(vr_context* ctx, int w, int h, const vr_partition* part);
+// tables of (w, h, part); part == NULL is the whole frame as rank 0 of 1
+int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out);
+// any cached table set of (w, h, world): the slot table does not depend on the rank
+int vr_partition_slot_tables(vr_context* ctx, int w, int h, int world, const PartTables** out);
 
 // ---- device helpers shared by kernels ---------------------------------------------------
 __device__ __forceinline__ float vr_max(float a, float b) { return a > b ? a : b; }

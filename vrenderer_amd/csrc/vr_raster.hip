@@ -785,6 +785,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
     for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
+    if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
     lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
@@ -991,7 +992,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
 
 // select -> vertex -> setup -> clip -> scan -> fill into `g`, on the geometry stream
 static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_from, const vr_view* view, const vr_render_params* rp,
-                           const RasterArgs& a)
+                           const RasterArgs& a, const PartTables* pt)
 {
     vr_context* ctx = t->ctx;
     hipStream_t s = ctx->stream, gs = t->geo_stream;
@@ -1040,9 +1041,9 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     { VrKernelScope ks(ctx, VR_K_CLIP, gs);
     hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count); }
     { VrKernelScope ks(ctx, VR_K_SCAN, gs);
-    const bool whole = a.world <= 1;
+    const bool whole = pt == nullptr;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity,
-                       whole ? (const int32_t*)nullptr : (const int32_t*)ctx->d_raster_tiles, whole ? n_tiles : ctx->num_raster_tiles, g.d_tile_order); }
+                       whole ? (const int32_t*)nullptr : (const int32_t*)pt->d_raster_tiles, whole ? n_tiles : pt->num_raster_tiles, g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
@@ -1068,6 +1069,8 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     VR_HIP(hipSetDevice(t->ctx->device));
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
+    const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
+    if (a.world > 1 && (rc = vr_partition_tables(t->ctx, gb->w, gb->h, part, &pt))) return rc;
     GeoSet& g = t->sets[t->cur ^ 1];
     g.prepared = false;
     // Start when the context's stream starts the tile pass queued last: the host runs frames ahead of the
@@ -1075,7 +1078,7 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     // with the previous frame's lighting pass (bandwidth-bound) instead of with a tile pass (which leaves
     // half of every CU's wave slots free).
     if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_raster_begin, 0));
-    if ((rc = launch_geometry(t, g, nullptr, view, rp, a))) return rc;
+    if ((rc = launch_geometry(t, g, nullptr, view, rp, a, pt))) return rc;
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
     return VR_OK;
 }
@@ -1091,7 +1094,8 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     hipStream_t s = ctx->stream;
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
-    if ((rc = vr_ensure_partition(ctx, gb->w, gb->h, part))) return rc;
+    const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
+    if (a.world > 1 && (rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt))) return rc;
 
     GeoSet& g = t->sets[t->cur ^ 1];
     const GeoSet& last = t->sets[t->cur];
@@ -1101,14 +1105,13 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     g.prepared = false;
     if (!use_prepared) {
         const GeoSet* sel = (rp->lock_view && last.have_selection) ? &last : nullptr;
-        if ((rc = launch_geometry(t, g, sel, view, rp, a))) return rc;
+        if ((rc = launch_geometry(t, g, sel, view, rp, a, pt))) return rc;
     }
     t->cur ^= 1;
     VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));                    // the tile pass consumes verts + bins
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
-    const bool whole = a.world <= 1;
-    const int grid = whole ? a.rtx * a.rty : ctx->num_raster_tiles;
+    const int grid = pt ? pt->num_raster_tiles : a.rtx * a.rty;
     VR_HIP(hipEventRecord(t->ev_raster_begin, s));
     t->raster_begin_recorded = true;
     if (grid > 0) {

@@ -376,14 +376,15 @@ static TmArgs make_args(const vr_tonemap_params* p, int w, int h)
 }
 
 // size checks of a (possibly packed) HDR source; returns the number of 256-lane blocks of the vector path
-static int source_blocks(vr_context* ctx, vr_image* hdr, int w, int h, const vr_partition* part, size_t* blocks)
+static int source_blocks(vr_context* ctx, vr_image* hdr, int w, int h, const vr_partition* part, size_t* blocks, const PartTables** tables)
 {
     VR_REQUIRE(w > 0 && h > 0, "bad frame size");
+    *tables = nullptr;
     if (part) {
-        int rc = vr_ensure_partition(ctx, w, h, part);
+        int rc = vr_partition_tables(ctx, w, h, part, tables);
         if (rc) return rc;
-        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr is smaller than vr_partition_packed_bytes()");
-        *blocks = (size_t)ctx->num_owned * 16;
+        VR_REQUIRE((size_t)(*tables)->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr is smaller than vr_partition_packed_bytes()");
+        *blocks = (size_t)(*tables)->num_owned * 16;
     } else {
         VR_REQUIRE((size_t)w * h * 8 <= hdr->capacity_bytes, "hdr is smaller than the frame");
         *blocks = ((size_t)w * h / 4 + 255) / 256;
@@ -400,13 +401,14 @@ extern "C" VR_API int vr_tonemap_add_frame_to_histogram(vr_tonemap* tm, const vr
     VR_REQUIRE(hdr->ctx->device == ctx->device, "image and tone-mapping pass live on different devices");
     VR_HIP(hipSetDevice(ctx->device));
     size_t blocks = 0;
-    if ((rc = source_blocks(ctx, hdr, w, h, part, &blocks))) return rc;
+    const PartTables* pt = nullptr;
+    if ((rc = source_blocks(ctx, hdr, w, h, part, &blocks, &pt))) return rc;
     const TmArgs a = make_args(p, w, h);
     VrKernelScope ks(ctx, VR_K_TM_HISTOGRAM);
     if (part) {
         if (blocks > 0)
             hipLaunchKernelGGL(k_tm_histogram<true>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
-                               ctx->d_owned_tiles, blocks, tm->d_hist);
+                               pt->d_owned_tiles, blocks, tm->d_hist);
     } else if (w % 4 == 0) {
         hipLaunchKernelGGL(k_tm_histogram<false>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
                            (const int32_t*)nullptr, blocks, tm->d_hist);
@@ -451,13 +453,14 @@ extern "C" VR_API int vr_tonemap_render(vr_tonemap* tm, const vr_tonemap_params*
     VR_REQUIRE(hdr->ctx->device == ctx->device, "image and tone-mapping pass live on different devices");
     VR_HIP(hipSetDevice(ctx->device));
     size_t blocks = 0;
-    if ((rc = source_blocks(ctx, hdr, w, h, part, &blocks))) return rc;
+    const PartTables* pt = nullptr;
+    if ((rc = source_blocks(ctx, hdr, w, h, part, &blocks, &pt))) return rc;
     const TmArgs a = make_args(p, w, h);
     VrKernelScope ks(ctx, VR_K_TONEMAP);
     if (part) {
-        VR_REQUIRE((size_t)ctx->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 3 <= ldr_capacity, "ldr buffer is smaller than vr_partition_packed_bytes_ldr()");
+        VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 3 <= ldr_capacity, "ldr buffer is smaller than vr_partition_packed_bytes_ldr()");
         if (blocks > 0)
-            hipLaunchKernelGGL(k_tonemap<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (const void*)hdr->data, ctx->d_owned_tiles,
+            hipLaunchKernelGGL(k_tonemap<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (const void*)hdr->data, pt->d_owned_tiles,
                                (const float*)tm->d_exposure, ldr, ctx->d_srgb_thr, ctx->d_enc_tab);
     } else {
         VR_REQUIRE((size_t)w * h * 4 <= ldr_capacity, "ldr buffer is smaller than the frame");
@@ -498,14 +501,14 @@ extern "C" VR_API int vr_tonemap_download(vr_tonemap* tm, uint32_t histogram[VR_
 extern "C" VR_API int vr_frame_detile_ldr(vr_context* ctx, const void* gathered, int32_t world, int32_t w, int32_t h, void* frame)
 {
     VR_REQUIRE(ctx && gathered && frame, "NULL argument");
-    VR_REQUIRE(ctx->part_world == world && ctx->part_w == w && ctx->part_h == h,
-               "vr_frame_detile_ldr needs this context's partition tables for the same frame size (vr_partition_prepare)");
-    VR_REQUIRE(w % 4 == 0, "frame width must be a multiple of 4");
+    VR_REQUIRE(w % 4 == 0 && w > 0 && h > 0 && world >= 1, "frame width must be a multiple of 4");
     VR_HIP(hipSetDevice(ctx->device));
+    const PartTables* pt = nullptr;
+    { int rc = vr_partition_slot_tables(ctx, w, h, world, &pt); if (rc) return rc; }
     const size_t quads = (size_t)w * h / 4;
     VrKernelScope ks(ctx, VR_K_DETILE_LDR);
     hipLaunchKernelGGL(k_detile_ldr, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)gathered,
-                       (uint4*)frame, w, h, (w + VR_OWNER_TILE - 1) / VR_OWNER_TILE, ctx->d_tile_slot);
+                       (uint4*)frame, w, h, (w + VR_OWNER_TILE - 1) / VR_OWNER_TILE, pt->d_tile_slot);
     VR_HIP(hipGetLastError());
     return VR_OK;
 }
