@@ -27,9 +27,7 @@ DEFERRED_BYTES_PER_PX = 36     # 28 B G-buffer read + 8 B RGBA16F write (SURVEY 
 GBUFFER_BYTES_PER_PX = 28      # G-buffer fill, per covered pixel
 
 
-def flythrough_camera(i, n=120, radius=600.0, height=250.0):
-    a = 2.0 * math.pi * (i % n) / n
-    return (radius * math.cos(a), height, radius * math.sin(a)), (0.0, 0.0, 0.0)
+from vrenderer_amd.scene import flythrough_camera  # noqa: E402
 
 
 def cpu_baseline(size, hm, al, params_fn, ambient, cam_fn):
@@ -139,7 +137,7 @@ def main():
 
     import vrenderer_amd as vr
     from vrenderer_amd.passes import frame_detile, frame_detile_ldr, partition_info, partition_prepare
-    from tests.common import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
+    from vrenderer_amd.scene import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
 
     W, H, size = args.width, args.height, args.size
     ctx = vr.Context(local_rank)

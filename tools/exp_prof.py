@@ -14,7 +14,7 @@ hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
 tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
 rt = vr.RenderTargets(ctx).Init(W, H)
 lib = capi.load_library()
-names = ["init", "setup(load+tri_setup)", "small sweeps", "big sweeps", "barrier wait", "resolve"]
+names = ["init", "fetch records", "tiny sweeps", "row sweeps", "big sweeps", "barrier wait", "resolve"]
 def run(name, view, **kw):
     rp = vr.default_render_params(400.0, **kw)
     buf = (C.c_ulonglong * 8)()
@@ -26,10 +26,11 @@ def run(name, view, **kw):
     ctx.synchronize()
     t = ctx.timing_collect(); ctx.timing_enable(False)
     lib.vr_debug_raster_prof(buf, 1)
-    tot = sum(buf[:6])
+    tot = sum(buf[:7])
     print(name, "k_raster %.1f us" % (t["k_raster"][0] / t["k_raster"][1] * 1e3),
           {n: "%.1f%%" % (100.0 * buf[i] / tot) for i, n in enumerate(names)},
-          "wave-cycles/launch %.3g" % (tot / N), flush=True)
+          "wave-cycles/launch %.3g" % (tot / N),
+          "triangles per launch: tiny %d, row %d, big %d" % ((buf[7] & 0xfffff) // N, ((buf[7] >> 20) & 0xfffff) // N, (buf[7] >> 40) // N), flush=True)
 for i in (30, 90):
     fly = vr.make_view(*flythrough_camera(i), W, H)
     run(f"fly{i} depth-only", fly, assume_cleared=1, depth_only=1)

@@ -49,6 +49,16 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
             int lo = 0, hi = 255;
             while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
             tab[b] = (uint8_t)lo;
+            // the device encoder adds at most one to tab[b]: no bucket may hold two thresholds
+            const uint32_t top = bits | 0xffffu;
+            float xt; memcpy(&xt, &top, 4);
+            int hi_code = 0;
+            for (int k = 255; k > 0; k--) if (xt >= c->h_srgb_thr[k]) { hi_code = k; break; }
+            if (b < kEncTabSize - 1 && hi_code - lo > 1) {
+                vr_set_error("sRGB encode table: bucket %d spans more than one threshold", b);
+                (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); delete c;
+                return VR_ERR_INVALID_ARGUMENT;
+            }
         }
         VR_HIP(hipMalloc(&c->d_enc_tab, (kEncTabSize + 3) / 4 * 4));          // read as dwords by the kernels
         VR_HIP(hipMemset(c->d_enc_tab, 0, (kEncTabSize + 3) / 4 * 4));

@@ -49,12 +49,13 @@ struct DevTex {
     const uint32_t* off;        // device table: byte offset of each level (kMaxLevels entries)
     int levels;
     int w0, h0;                 // level l is max(1, w0 >> l) x max(1, h0 >> l)
-    int pad;
+    uint32_t chain_bytes;       // bytes of the mip chain at `base` (bound of the buffer resource the tile pass reads texels through)
     // R8 textures only: per level a (w+2) x (h+2) table of bilinear footprints.  Entry (ix, iy)
     // packs the four clamp-addressed texels (x0,y0) (x1,y0) (x0,y1) (x1,y1) for floor(x) = ix-1,
     // floor(y) = iy-1 into one dword, so a bilinear tap is ONE load instead of four byte loads.
     const uint32_t* quad;
     const uint32_t* qoff;       // device table: dword offset of each level's quad table
+    uint32_t quad_bytes, pad;   // bytes of all quad tables at `quad`
 };
 
 // Per-light constants the deferred kernel reads (host precomputes the half-angle terms).
@@ -155,6 +156,7 @@ struct GeoSet {
     uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled
+    uint4* d_recs = nullptr;             // per surviving triangle: its set-up record (9 x 16 B), then the clipper's (hard_cap * 4)
     uint32_t* d_hard_list = nullptr;     // triangle ids that need the clipper
     HardTriRec* d_hard_tris = nullptr;   // capacity hard_cap * 4
     uint32_t* d_hard_first = nullptr;    // per regular triangle id: first HardTriRec index

@@ -239,11 +239,77 @@ __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1
     return (uint64_t)(uint32_t)tx0 | ((uint64_t)(uint32_t)ty0 << 16) | ((uint64_t)(uint32_t)tx1 << 32) | ((uint64_t)(uint32_t)ty1 << 48);
 }
 
-// raster-tile rectangle a triangle touches, or ~0 when it is culled
-__device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2)
+// Perspective-correct world xz at a pixel centre and its screen-space derivatives (analytic
+// derivative of the same interpolant; feeds the implicit LOD of Texture2D::Sample).
+struct TriDeriv { float dl1dx, dl2dx, dl1dy, dl2dy; };      // per-pixel steps of the barycentrics
+
+__device__ __forceinline__ TriDeriv tri_derivs(const TriSetup& t)
+{
+    // (float)(A * 256) == (float)A * 256 exactly (power-of-two scaling)
+    TriDeriv d;
+    d.dl1dx = ((float)t.A1 * 256.0f) * t.inv_area; d.dl2dx = ((float)t.A2 * 256.0f) * t.inv_area;
+    d.dl1dy = ((float)t.B1 * 256.0f) * t.inv_area; d.dl2dy = ((float)t.B2 * 256.0f) * t.inv_area;
+    return d;
+}
+
+// Triangle record: everything the tile pass needs of a triangle that survived culling, written once by
+// k_setup (regular triangles, index = triangle id) or k_clip (clipper output, index = kRecHardBase-relative)
+// and read by both phases of k_raster, so neither re-derives the set-up from the vertices.  Nine 16-byte
+// groups (144 B):
+//   0: A0 B0 C0(lo hi)        edge 0            (coverage)
+//   1: A1 B1 C1(lo hi)        edge 1            (coverage + barycentric l1)
+//   2: A2 B2 C2(lo hi)        edge 2            (coverage + barycentric l2)
+//   3: z0 dz1 dz2 inv_area    depth plane       (coverage)
+//   4: box0 box1 flags -      pixel box (x | y << 16, inclusive, clamped to the viewport); flags: bias0..2, bit 3 = small
+//   5: iw0 iw1 iw2 ddenx      1/w per vertex;   the per-triangle terms of the interpolant's screen-space
+//   6: wx0 wx1 wx2 ddeny      world x           derivative (what interp_attr computed per pixel from constants)
+//   7: wz0 wz1 wz2 inv_area   world z
+//   8: nxx nzx nxy nzy
+// small = every |A_i|, |B_i| <= 2^14 (edges up to 64 pixels): every edge value at a pixel of a tile the triangle
+// touches then fits 31 bits (|E(P)| <= 2^29 inside its box, + 64 pixels * 256 * (|A|+|B|) <= 2^29 to any pixel of
+// the tile), and 256*B fits 24 bits, so the tile pass runs such triangles in int32 / mad24.
+constexpr int kRecGroups = 9;
+constexpr int32_t kSmallEdge = 1 << 14;
+
+__device__ __forceinline__ void write_tri_rec(uint4* __restrict__ dst, const TriSetup& t, const ScreenVert& s0, const ScreenVert& s1,
+                                              const ScreenVert& s2)
+{
+    const TriDeriv td = tri_derivs(t);
+    float ddenx, nxx, nzx, ddeny, nxy, nzy;
+    {
+        const float dl1 = td.dl1dx, dl2 = td.dl2dx, dl0 = (0.0f - dl1) - dl2;
+        const float dq0 = dl0 * s0.iw, dq1 = dl1 * s1.iw, dq2 = dl2 * s2.iw;
+        ddenx = (dq0 + dq1) + dq2;
+        nxx = (dq0 * s0.wx + dq1 * s1.wx) + dq2 * s2.wx; nzx = (dq0 * s0.wz + dq1 * s1.wz) + dq2 * s2.wz;
+    }
+    {
+        const float dl1 = td.dl1dy, dl2 = td.dl2dy, dl0 = (0.0f - dl1) - dl2;
+        const float dq0 = dl0 * s0.iw, dq1 = dl1 * s1.iw, dq2 = dl2 * s2.iw;
+        ddeny = (dq0 + dq1) + dq2;
+        nxy = (dq0 * s0.wx + dq1 * s1.wx) + dq2 * s2.wx; nzy = (dq0 * s0.wz + dq1 * s1.wz) + dq2 * s2.wz;
+    }
+    const int32_t m = max(max(max(abs(t.A0), abs(t.B0)), max(abs(t.A1), abs(t.B1))), max(abs(t.A2), abs(t.B2)));
+    const uint32_t flags = (uint32_t)t.bias0 | ((uint32_t)t.bias1 << 1) | ((uint32_t)t.bias2 << 2) | (m <= kSmallEdge ? 8u : 0u);
+#define F2U(x) __float_as_uint(x)
+    dst[0] = make_uint4((uint32_t)t.A0, (uint32_t)t.B0, (uint32_t)(uint64_t)t.C0, (uint32_t)((uint64_t)t.C0 >> 32));
+    dst[1] = make_uint4((uint32_t)t.A1, (uint32_t)t.B1, (uint32_t)(uint64_t)t.C1, (uint32_t)((uint64_t)t.C1 >> 32));
+    dst[2] = make_uint4((uint32_t)t.A2, (uint32_t)t.B2, (uint32_t)(uint64_t)t.C2, (uint32_t)((uint64_t)t.C2 >> 32));
+    dst[3] = make_uint4(F2U(t.z0), F2U(t.dz1), F2U(t.dz2), F2U(t.inv_area));
+    dst[4] = make_uint4((uint32_t)t.x0 | ((uint32_t)t.y0 << 16), (uint32_t)t.x1 | ((uint32_t)t.y1 << 16), flags, 0u);
+    dst[5] = make_uint4(F2U(s0.iw), F2U(s1.iw), F2U(s2.iw), F2U(ddenx));
+    dst[6] = make_uint4(F2U(s0.wx), F2U(s1.wx), F2U(s2.wx), F2U(ddeny));
+    dst[7] = make_uint4(F2U(s0.wz), F2U(s1.wz), F2U(s2.wz), F2U(t.inv_area));
+    dst[8] = make_uint4(F2U(nxx), F2U(nzx), F2U(nxy), F2U(nzy));
+#undef F2U
+}
+
+// Sets a triangle up against the viewport: its raster-tile rectangle, or ~0 when it is culled; a surviving
+// triangle leaves its record at `rec`.
+__device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVert s0, ScreenVert s1, ScreenVert s2, uint4* __restrict__ rec)
 {
     TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, a.wireframe != 0);
     if (!t.visible) return ~0ull;
+    write_tri_rec(rec, t, s0, s1, s2);          // tri_setup has put the vertices into clockwise order
     return pack_rect(t.x0 >> a.tile_shift, t.y0 >> a.tile_shift, t.x1 >> a.tile_shift, t.y1 >> a.tile_shift);
 }
 
@@ -293,7 +359,7 @@ __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
                                                 uint64_t* __restrict__ rect, uint32_t* __restrict__ hard_list,
-                                                uint32_t* __restrict__ tile_count)
+                                                uint32_t* __restrict__ tile_count, uint4* __restrict__ recs)
 {
     const uint32_t total = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < total; tri += gridDim.x * blockDim.x) {
@@ -320,7 +386,7 @@ __global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __re
                 const uint32_t slot = atomicAdd(&counters[C_HARDLIST], 1u);
                 if (slot < a.hard_cap) hard_list[slot] = tri; else atomicOr(&counters[C_FLAGS], 2u);
             } else {
-                r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2));
+                r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), recs + (size_t)tri * kRecGroups);
             }
         }
         bin_rect<false>(a, r, 0u, tile_count, nullptr);
@@ -372,7 +438,8 @@ __device__ int clip_poly(ClipVert* poly, int n, int plane)
 
 __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
                                               const uint32_t* __restrict__ hard_list, HardTriRec* __restrict__ hard_tris,
-                                              uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count)
+                                              uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count,
+                                              uint4* __restrict__ hard_recs)
 {
     const uint32_t n_hard = min(counters[C_HARDLIST], a.hard_cap);
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_hard; h += gridDim.x * blockDim.x) {
@@ -416,7 +483,8 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
             HardTriRec rec;
             rec.v0 = a.extra_vert_base + vbase; rec.v1 = rec.v0 + s + 1; rec.v2 = rec.v0 + s + 2;
             rec.order_key = (tri << 4) | (s << 1) | 1u;
-            const uint64_t r = triangle_rect(a, load_sv(verts, rec.v0), load_sv(verts, rec.v1), load_sv(verts, rec.v2));
+            const uint64_t r = triangle_rect(a, load_sv(verts, rec.v0), load_sv(verts, rec.v1), load_sv(verts, rec.v2),
+                                             hard_recs + (size_t)(tbase + s) * kRecGroups);
             if (r != ~0ull) {       // rare path, divergent loop: plain per-tile atomics
                 const int qx0 = (int)(r & 0xffffu), qy0 = (int)((r >> 16) & 0xffffu), qx1 = (int)((r >> 32) & 0xffffu), qy1 = (int)((r >> 48) & 0xffffu);
                 for (int ty = qy0; ty <= qy1; ty++)
@@ -500,8 +568,16 @@ __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// k_raster: one workgroup per 64x64 raster tile
+// k_raster: one workgroup per 64x64 (or 32x32) raster tile
 // ---------------------------------------------------------------------------------------
+// record index of a bin entry: the triangle id, or - for clipper output - its slot in the records' extra region
+__device__ __forceinline__ size_t rec_index(uint32_t key, const uint32_t* __restrict__ hard_first, uint32_t rec_hard_base)
+{
+    const uint32_t tri = key >> 4;
+    if (key & 1u) return (size_t)rec_hard_base + hard_first[tri] + ((key >> 1) & 7u);
+    return (size_t)tri;
+}
+
 __device__ __forceinline__ void entry_vertices(uint32_t key, const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                uint32_t& i0, uint32_t& i1, uint32_t& i2)
 {
@@ -518,49 +594,9 @@ __device__ __forceinline__ int64_t edge_eval(int32_t A, int32_t B, int64_t C, in
 {
     return (int64_t)A * PX + ((int64_t)B * PY + C);
 }
+__device__ __forceinline__ int64_t rec_c(const uint4& g) { return (int64_t)(((uint64_t)g.w << 32) | (uint64_t)g.z); }
 
-// Perspective-correct world xz at a pixel centre and its screen-space derivatives (analytic
-// derivative of the same interpolant; feeds the implicit LOD of Texture2D::Sample).
 struct Attr { float wx, wz, dwxdx, dwzdx, dwxdy, dwzdy; };
-struct TriDeriv { float dl1dx, dl2dx, dl1dy, dl2dy; };      // per-pixel steps of the barycentrics
-
-__device__ __forceinline__ TriDeriv tri_derivs(const TriSetup& t)
-{
-    // (float)(A * 256) == (float)A * 256 exactly (power-of-two scaling)
-    TriDeriv d;
-    d.dl1dx = ((float)t.A1 * 256.0f) * t.inv_area; d.dl2dx = ((float)t.A2 * 256.0f) * t.inv_area;
-    d.dl1dy = ((float)t.B1 * 256.0f) * t.inv_area; d.dl2dy = ((float)t.B2 * 256.0f) * t.inv_area;
-    return d;
-}
-
-__device__ __forceinline__ Attr interp_attr(const ScreenVert& v0, const ScreenVert& v1, const ScreenVert& v2, float inv_area,
-                                            const TriDeriv& td, int64_t E1, int64_t E2)
-{
-    const float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
-    const float l0 = (1.0f - l1) - l2;
-    const float q0 = l0 * v0.iw, q1 = l1 * v1.iw, q2 = l2 * v2.iw;
-    const float den = (q0 + q1) + q2;
-    const float r = 1.0f / den;
-    const float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
-    Attr o;
-    o.wx = (b0 * v0.wx + b1 * v1.wx) + b2 * v2.wx;
-    o.wz = (b0 * v0.wz + b1 * v1.wz) + b2 * v2.wz;
-    {
-        const float dl1 = td.dl1dx, dl2 = td.dl2dx, dl0 = (0.0f - dl1) - dl2;
-        const float dq0 = dl0 * v0.iw, dq1 = dl1 * v1.iw, dq2 = dl2 * v2.iw;
-        const float dden = (dq0 + dq1) + dq2;
-        const float nx = (dq0 * v0.wx + dq1 * v1.wx) + dq2 * v2.wx, nz = (dq0 * v0.wz + dq1 * v1.wz) + dq2 * v2.wz;
-        o.dwxdx = (nx - o.wx * dden) * r; o.dwzdx = (nz - o.wz * dden) * r;
-    }
-    {
-        const float dl1 = td.dl1dy, dl2 = td.dl2dy, dl0 = (0.0f - dl1) - dl2;
-        const float dq0 = dl0 * v0.iw, dq1 = dl1 * v1.iw, dq2 = dl2 * v2.iw;
-        const float dden = (dq0 + dq1) + dq2;
-        const float nx = (dq0 * v0.wx + dq1 * v1.wx) + dq2 * v2.wx, nz = (dq0 * v0.wz + dq1 * v1.wz) + dq2 * v2.wz;
-        o.dwxdy = (nx - o.wx * dden) * r; o.dwzdy = (nz - o.wz * dden) * r;
-    }
-    return o;
-}
 
 // (x + half) / world_size; when world_size is a power of two the division is an exact
 // scaling, so the multiplication by its reciprocal gives the identical float.
@@ -586,7 +622,10 @@ __device__ __forceinline__ void srgb_filter(uint32_t p00, uint32_t p10, uint32_t
 // per-level offset tables (no dependent global load in front of a texel fetch).  The finer level of
 // the four height taps and of the albedo tap is fetched as one batch of 8 loads; the coarser level
 // (only when a LOD fraction is non-zero) as a second batch.
-__device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, const float* __restrict__ lut,
+// Texels are fetched through buffer resources (rq: the quad tables, rc: the albedo chain): a fetch's address is one
+// 32-bit byte offset (1 VALU) instead of a 64-bit pointer sum (3), and an out-of-range offset reads 0 instead of faulting.
+__device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq,
+                                             __amdgpu_buffer_rsrc_t rc, const float* __restrict__ lut,
                                              const float* __restrict__ thr, const uint8_t* __restrict__ enc, const float* __restrict__ r8,
                                              const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
@@ -601,25 +640,29 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     float hgt[4], col[3];
     {
         const int w = max(1, hm.w0 >> lh.l0), h = max(1, hm.h0 >> lh.l0), wc = max(1, al.w0 >> lc.l0), hc = max(1, al.h0 >> lc.l0);
-        const uint32_t* q = hm.quad + qoff[lh.l0];
-        const uint32_t* c = (const uint32_t*)(al.base + aoff[lc.l0]);
+        const uint32_t q = qoff[lh.l0], c = aoff[lc.l0];        // dword offset of the quad table, byte offset of the albedo level
         const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
         const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
-        const uint32_t e0 = q[t0.idx], e1 = q[t1.idx], e2 = q[t2.idx], e3 = q[t3.idx];
-        const uint32_t p00 = c[s.i00], p10 = c[s.i10], p01 = c[s.i01], p11 = c[s.i11];
+#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b32(rq, (q + (i)) << 2, 0, 0)
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
+        const uint32_t e0 = LDQ(t0.idx), e1 = LDQ(t1.idx), e2 = LDQ(t2.idx), e3 = LDQ(t3.idx);
+        const uint32_t p00 = LDC(s.i00), p10 = LDC(s.i10), p01 = LDC(s.i01), p11 = LDC(s.i11);
         hgt[0] = quad_filter(e0, t0, r8); hgt[1] = quad_filter(e1, t1, r8); hgt[2] = quad_filter(e2, t2, r8); hgt[3] = quad_filter(e3, t3, r8);
         srgb_filter(p00, p10, p01, p11, s, lut, col);
     }
-    if (lh.f > 0.0f || lc.f > 0.0f) {
+    // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
+    // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
+    if (__any(lh.f > 0.0f || lc.f > 0.0f)) {
         // blending with a zero fraction returns the finer sample exactly, so one branch serves both textures
         const int l1h = min(lh.l0 + 1, hm.levels - 1), l1c = min(lc.l0 + 1, al.levels - 1);
         const int w = max(1, hm.w0 >> l1h), h = max(1, hm.h0 >> l1h), wc = max(1, al.w0 >> l1c), hc = max(1, al.h0 >> l1c);
-        const uint32_t* q = hm.quad + qoff[l1h];
-        const uint32_t* c = (const uint32_t*)(al.base + aoff[l1c]);
+        const uint32_t q = qoff[l1h], c = aoff[l1c];
         const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
         const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
-        const uint32_t e0 = q[t0.idx], e1 = q[t1.idx], e2 = q[t2.idx], e3 = q[t3.idx];
-        const uint32_t p00 = c[s.i00], p10 = c[s.i10], p01 = c[s.i01], p11 = c[s.i11];
+        const uint32_t e0 = LDQ(t0.idx), e1 = LDQ(t1.idx), e2 = LDQ(t2.idx), e3 = LDQ(t3.idx);
+        const uint32_t p00 = LDC(s.i00), p10 = LDC(s.i10), p01 = LDC(s.i01), p11 = LDC(s.i11);
+#undef LDQ
+#undef LDC
         const float g0 = quad_filter(e0, t0, r8), g1 = quad_filter(e1, t1, r8), g2 = quad_filter(e2, t2, r8), g3 = quad_filter(e3, t3, r8);
         float cb[3];
         srgb_filter(p00, p10, p01, p11, s, lut, cb);
@@ -645,8 +688,12 @@ __device__ __forceinline__ uint32_t order_of(uint32_t key) { return ~(key + 1u);
 __device__ __forceinline__ uint32_t key_of(uint32_t order) { return ~order - 1u; }
 
 constexpr int kSmallArea = 16;     // triangles whose tile-clipped bbox has <= 16 pixels are rasterised by one lane
-constexpr int kDenseWave = 32, kSmallAreaDense = 128;
-constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)   // ... <= 128 pixels when at least half of the wave's lanes hold an entry
+constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels when at least half of the wave's lanes hold an entry
+#ifndef VR_ROW_MIN
+#define VR_ROW_MIN 8
+#endif
+constexpr int kRowMin = VR_ROW_MIN;  // the row hand-out needs this many eligible triangles in a wave (its scan + fetches are a fixed cost)
+constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)
 
 // Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
 // of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
@@ -714,25 +761,26 @@ __device__ __forceinline__ int64_t floor_div64(int64_t num, int64_t den)
 // [min, max) of the major axis: the pixel that contains the exact line point there.  The pixel is a
 // sample of the triangle's plane at its centre (depth, attributes), so the resolve below is shared
 // with fill mode.  Debug mode: one lane per triangle, no wave cooperation.
+struct WirePlane { int32_t A1, B1, A2, B2; int64_t C1, C2; float z0, dz1, dz2, inv_area; };
 template <int TILE>
-__device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, const ScreenVert& va, const ScreenVert& vb, const TriSetup& t,
+__device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, int32_t aX, int32_t aY, int32_t bX, int32_t bY, const WirePlane& t,
                                         int ox, int oy, int bx0, int by0, int bx1, int by1, uint32_t ord)
 {
-    const int64_t dX = (int64_t)vb.X - va.X, dY = (int64_t)vb.Y - va.Y;
+    const int64_t dX = (int64_t)bX - aX, dY = (int64_t)bY - aY;
     if (dX == 0 && dY == 0) return;
     const bool xmajor = llabs(dX) >= llabs(dY);
-    const int32_t ca = xmajor ? va.X : va.Y, cb = xmajor ? vb.X : vb.Y;
+    const int32_t ca = xmajor ? aX : aY, cb = xmajor ? bX : bY;
     const int32_t lo = min(ca, cb), hi = max(ca, cb);
     const int p0 = max((lo - 128 + 255) >> 8, xmajor ? bx0 : by0), p1 = min(((hi - 128 + 255) >> 8) - 1, xmajor ? bx1 : by1);
     for (int p = p0; p <= p1; p++) {
         const int64_t P = (int64_t)p * 256 + 128;
         int px, py;
         if (xmajor) {
-            const int64_t q = floor_div64((int64_t)va.Y * dX + (P - va.X) * dY, dX * 256);
+            const int64_t q = floor_div64((int64_t)aY * dX + (P - aX) * dY, dX * 256);
             if (q < by0 || q > by1) continue;
             px = p; py = (int)q;
         } else {
-            const int64_t q = floor_div64((int64_t)va.X * dY + (P - va.Y) * dX, dY * 256);
+            const int64_t q = floor_div64((int64_t)aX * dY + (P - aY) * dX, dY * 256);
             if (q < bx0 || q > bx1) continue;
             px = (int)q; py = p;
         }
@@ -750,6 +798,7 @@ __device__ unsigned long long g_raster_prof[kProfBlocks * 8];
 #define VR_PROF_MARK(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) { const unsigned long long now_ = __builtin_readcyclecounter(); \
                                  atomicAdd(&g_raster_prof[blockIdx.x * 8 + (i)], now_ - prof_t_); prof_t_ = __builtin_readcyclecounter(); } } while (0)
 #define VR_PROF_BEGIN unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define VR_PROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) atomicAdd(&g_raster_prof[blockIdx.x * 8 + (i)], (unsigned long long)(v)); } while (0)
 extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
 {
     static unsigned long long host[kProfBlocks * 8];
@@ -762,11 +811,13 @@ extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
 #else
 #define VR_PROF_MARK(i) do { } while (0)
 #define VR_PROF_BEGIN do { } while (0)
+#define VR_PROF_ADD(i, v) do { } while (0)
 #endif
 
 template <bool WIRE, int TILE>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
+                                                 const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
                                                  const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
@@ -777,18 +828,19 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __shared__ unsigned long long vis[TILE * TILE];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float lut[256];
-    __shared__ float thr[256];
+    __shared__ float thr[kThrTabSize];
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
-    if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
-    for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
+    if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
+    for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
     lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
+    if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     for (int i = tid; i < TILE * TILE; i += 256) {
         const int lx = i & (TILE - 1), ly = i / TILE;
@@ -811,76 +863,143 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         const uint32_t idx = base + (uint32_t)(lane * 4 + wave);
         bool valid = idx < n && (off + idx) < a.bin_capacity;
         uint32_t key = 0;
-        TriSetup t; t.visible = false;
+        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
         if (valid) {
             key = entries[off + idx];
-            uint32_t i0, i1, i2;
-            entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
-            ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
-            t = tri_setup(s0, s1, s2, a.mirrored, bx0, by0, bx1, by1, WIRE);
-            if (WIRE && t.visible) {
-                wire_edge<TILE>(vis, s0, s1, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
-                wire_edge<TILE>(vis, s1, s2, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
-                wire_edge<TILE>(vis, s2, s0, t, ox, oy, bx0, by0, bx1, by1, order_of(key));
-                t.visible = false;          // covered; skip the fill sweeps
-            }
+            const uint4* __restrict__ rp = recs + rec_index(key, hard_first, rec_hard_base) * kRecGroups;
+            g0 = rp[0]; g1 = rp[1]; g2 = rp[2]; g3 = rp[3]; g4 = rp[4];
         }
-        valid = valid && t.visible;
-        VR_PROF_MARK(1);
+        const int32_t A0 = (int32_t)g0.x, B0 = (int32_t)g0.y, A1 = (int32_t)g1.x, B1 = (int32_t)g1.y, A2 = (int32_t)g2.x, B2 = (int32_t)g2.y;
+        const int64_t C0 = rec_c(g0), C1 = rec_c(g1), C2 = rec_c(g2);
+        const float z0 = __uint_as_float(g3.x), dz1 = __uint_as_float(g3.y), dz2 = __uint_as_float(g3.z), ia = __uint_as_float(g3.w);
+        const int bias0 = (int)(g4.z & 1u), bias1 = (int)((g4.z >> 1) & 1u), bias2 = (int)((g4.z >> 2) & 1u);
+        const bool is_small = (g4.z & 8u) != 0u;
+        // the triangle's pixel box inside this tile (never empty for a binned triangle; checked all the same)
+        const int tx0 = max((int)(g4.x & 0xffffu), bx0), ty0 = max((int)(g4.x >> 16), by0);
+        const int tx1 = min((int)(g4.y & 0xffffu), bx1), ty1 = min((int)(g4.y >> 16), by1);
+        valid = valid && tx0 <= tx1 && ty0 <= ty1;
         const uint32_t order = order_of(key);
+        if (WIRE) {
+            if (valid) {
+                uint32_t i0, i1, i2;
+                entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
+                const ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
+                WirePlane wp; wp.A1 = A1; wp.B1 = B1; wp.A2 = A2; wp.B2 = B2; wp.C1 = C1; wp.C2 = C2; wp.z0 = z0; wp.dz1 = dz1; wp.dz2 = dz2; wp.inv_area = ia;
+                wire_edge<TILE>(vis, s0.X, s0.Y, s1.X, s1.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
+                wire_edge<TILE>(vis, s1.X, s1.Y, s2.X, s2.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
+                wire_edge<TILE>(vis, s2.X, s2.Y, s0.X, s0.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
+            }
+            continue;                   // covered; no fill sweeps
+        }
+        VR_PROF_MARK(1);
         // tile-relative form
-        const int64_t e0 = edge_eval(t.A0, t.B0, t.C0, PX0, PY0), e1 = edge_eval(t.A1, t.B1, t.C1, PX0, PY0), e2 = edge_eval(t.A2, t.B2, t.C2, PX0, PY0);
-        const int64_t sx0 = (int64_t)t.A0 * 256, sy0 = (int64_t)t.B0 * 256, sx1 = (int64_t)t.A1 * 256, sy1 = (int64_t)t.B1 * 256;
-        const int64_t sx2 = (int64_t)t.A2 * 256, sy2 = (int64_t)t.B2 * 256;
-        const int64_t lim = (int64_t)1 << 30;
-        const int64_t span0 = (kRasterTile + 8) * (llabs(sx0) + llabs(sy0)), span1 = (kRasterTile + 8) * (llabs(sx1) + llabs(sy1));
-        const int64_t span2 = (kRasterTile + 8) * (llabs(sx2) + llabs(sy2));
-        const bool fits32 = valid && llabs(e0) + span0 < lim && llabs(e1) + span1 < lim && llabs(e2) + span2 < lim;
-        const int x0 = t.x0 - ox, y0 = t.y0 - oy, x1 = t.x1 - ox, y1 = t.y1 - oy;      // tile-local, inclusive
+        const int64_t e0 = edge_eval(A0, B0, C0, PX0, PY0), e1 = edge_eval(A1, B1, C1, PX0, PY0), e2 = edge_eval(A2, B2, C2, PX0, PY0);
+        const int x0 = tx0 - ox, y0 = ty0 - oy, x1 = tx1 - ox, y1 = ty1 - oy;      // tile-local, inclusive
         const int bw = valid ? x1 - x0 + 1 : 0, bh = valid ? y1 - y0 + 1 : 0;
-        // One lane per triangle pays when the wave's lanes are mostly busy (dense bins: low resolutions, distant terrain);
-        // with a handful of entries per wave the cooperative sweep wins for anything but tiny boxes (measured: 1080p -20 %).
+        // One lane per triangle pays when the wave's lanes are mostly busy (dense bins: low resolutions, distant terrain)
+        // or the box is tiny; everything else is handed out row by row (small triangles) or swept by the whole wave.
         const int n_wave = __popcll(__ballot(valid));
-        const bool small = valid && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
-        if (small) {
-            if (fits32) sweep_small<int32_t, TILE>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, (int32_t)sx0, (int32_t)sy0, (int32_t)sx1, (int32_t)sy1,
-                                             (int32_t)sx2, (int32_t)sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1, t.z0, t.dz1, t.dz2, t.inv_area, order);
-            else sweep_small<int64_t, TILE>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, t.bias0, t.bias1, t.bias2, x0, y0, x1, y1,
-                                      t.z0, t.dz1, t.dz2, t.inv_area, order);
+        const bool tiny = valid && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
+        // int32 steps (x 256 exact in 32 bits for every small triangle)
+        // (unsigned arithmetic: the products of a triangle that does not fit are never used, but must not be undefined)
+#define MUL256(v) ((int32_t)((uint32_t)(v) * 256u))
+        const int32_t sx0 = MUL256(A0), sy0 = MUL256(B0), sx1 = MUL256(A1), sy1 = MUL256(B1), sx2 = MUL256(A2), sy2 = MUL256(B2);
+        bool fits32 = is_small;
+        if (valid && !is_small) {
+            const int64_t lim = (int64_t)1 << 30;
+            const int64_t w0 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A0) + llabs((int64_t)B0));
+            const int64_t w1 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A1) + llabs((int64_t)B1));
+            const int64_t w2 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A2) + llabs((int64_t)B2));
+            fits32 = llabs(e0) + w0 < lim && llabs(e1) + w1 < lim && llabs(e2) + w2 < lim;
+        }
+        if (tiny) {
+            if (fits32) sweep_small<int32_t, TILE>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, sx0, sy0, sx1, sy1, sx2, sy2,
+                                                    bias0, bias1, bias2, x0, y0, x1, y1, z0, dz1, dz2, ia, order);
+            else sweep_small<int64_t, TILE>(vis, e0, e1, e2, (int64_t)A0 * 256, (int64_t)B0 * 256, (int64_t)A1 * 256, (int64_t)B1 * 256,
+                                             (int64_t)A2 * 256, (int64_t)B2 * 256, bias0, bias1, bias2, x0, y0, x1, y1, z0, dz1, dz2, ia, order);
         }
         VR_PROF_MARK(2);
-        // big triangles: broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its bbox
-        unsigned long long big = __ballot(valid && !small);
+        bool rowp = false;
+        // ---- small triangles, row by row (only when the wave holds enough of them to repay the hand-out; a few are
+        // cheaper through the cooperative sweep below): the wave's rows are numbered through (prefix sum of the box heights) and
+        // handed to the lanes 64 at a time; a lane fetches its row's triangle from the owning lane (ds_bpermute) and walks
+        // the row's pixels.  Lane utilisation no longer depends on how many triangles the bin holds or how they are shaped.
+        const bool row_ok = valid && !tiny && is_small;
+        if (__popcll(__ballot(row_ok)) >= kRowMin) {
+            rowp = row_ok;
+            const int rows = rowp ? bh : 0;
+            int incl = rows;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            const int R = __builtin_amdgcn_readlane(incl, 63);
+            if (R > 0) {        // (uniform: nothing below runs for a wave without row work)
+                // biased edge values at the box's first pixel; E_i - bias_i >= 0 <=> inside
+                const int32_t f0 = ((int32_t)e0 + __mul24(sy0, y0)) + (__mul24(sx0, x0) - bias0);
+                const int32_t f1 = ((int32_t)e1 + __mul24(sy1, y0)) + (__mul24(sx1, x0) - bias1);
+                const int32_t f2 = ((int32_t)e2 + __mul24(sy2, y0)) + (__mul24(sx2, x0) - bias2);
+                const int start = incl - rows;
+                const uint32_t xb = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)bias1 << 24) | ((uint32_t)bias2 << 25);
+                for (int cb = 0; cb < R; cb += 64) {
+                    const int r = cb + lane;
+                    int tl = 0;                                   // number of lanes whose rows end at or before r = the owning lane
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) { const int v = __shfl(incl, tl + step - 1); if (v <= r) tl += step; }
+                    const bool act = r < R;
+                    tl = min(tl, 63);
+                    const int j = r - __shfl(start, tl);          // row inside the triangle's box
+                    const uint32_t qb = (uint32_t)__shfl((int)xb, tl);
+                    const int32_t qx0 = __shfl(sx0, tl), qx1 = __shfl(sx1, tl), qx2 = __shfl(sx2, tl);
+                    int32_t v0 = __shfl(f0, tl) + __mul24(__shfl(sy0, tl), j);
+                    int32_t v1 = __shfl(f1, tl) + __mul24(__shfl(sy1, tl), j);
+                    int32_t v2 = __shfl(f2, tl) + __mul24(__shfl(sy2, tl), j);
+                    const float qz0 = __shfl(z0, tl), qdz1 = __shfl(dz1, tl), qdz2 = __shfl(dz2, tl), qia = __shfl(ia, tl);
+                    const uint32_t qord = (uint32_t)__shfl((int)order, tl);
+                    const int qb1 = (int)((qb >> 24) & 1u), qb2 = (int)((qb >> 25) & 1u);
+                    const int y = (int)((qb >> 16) & 255u) + j, xe = (int)((qb >> 8) & 255u);
+                    int x = (int)(qb & 255u);
+                    while (__any(act && x <= xe)) {
+                        if (act && x <= xe && (v0 | v1 | v2) >= 0) cover_pixel<int32_t, TILE>(vis, x, y, v1, v2, qb1, qb2, qz0, qdz1, qdz2, qia, qord);
+                        v0 += qx0; v1 += qx1; v2 += qx2; x++;
+                    }
+                }
+            }
+        }
+        VR_PROF_MARK(3);
+        // big triangles (an edge longer than 64 pixels): broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its bbox
+        unsigned long long big = __ballot(valid && !tiny && !rowp);
+        VR_PROF_ADD(7, ((unsigned long long)__popcll(big) << 40) | ((unsigned long long)__popcll(__ballot(rowp)) << 20) | (unsigned long long)__popcll(__ballot(tiny)));
         const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
-        const uint32_t misc = (uint32_t)t.bias0 | ((uint32_t)t.bias1 << 1) | ((uint32_t)t.bias2 << 2) | (fits32 ? 8u : 0u);
+        const uint32_t misc = (uint32_t)bias0 | ((uint32_t)bias1 << 1) | ((uint32_t)bias2 << 2) | (fits32 ? 8u : 0u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
 #define BC(v) __builtin_amdgcn_readlane((int)(v), src)
 #define BC64(v) (((int64_t)BC((int32_t)((v) >> 32)) << 32) | (int64_t)(uint32_t)BC((int32_t)(uint32_t)(v)))
             const uint32_t m = (uint32_t)BC(misc), bx = (uint32_t)BC(box), ord = (uint32_t)BC(order);
-            const float z0 = __int_as_float(BC(__float_as_int(t.z0))), dz1 = __int_as_float(BC(__float_as_int(t.dz1)));
-            const float dz2 = __int_as_float(BC(__float_as_int(t.dz2))), ia = __int_as_float(BC(__float_as_int(t.inv_area)));
+            const float bz0 = __int_as_float(BC(__float_as_int(z0))), bdz1 = __int_as_float(BC(__float_as_int(dz1)));
+            const float bdz2 = __int_as_float(BC(__float_as_int(dz2))), bia = __int_as_float(BC(__float_as_int(ia)));
             const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
-            const int tx0 = bx & 255u, ty0 = (bx >> 8) & 255u, tx1 = (bx >> 16) & 255u, ty1 = bx >> 24;
+            const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
             if (m & 8u) {
-                sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC((int32_t)sx0), BC((int32_t)sy0),
-                                   BC((int32_t)sx1), BC((int32_t)sy1), BC((int32_t)sx2), BC((int32_t)sy2), b0, b1, b2, tx0, ty0, tx1, ty1,
-                                   z0, dz1, dz2, ia, ord);
+                sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
+                                   BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
             } else {
-                sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), BC64(sx0), BC64(sy0), BC64(sx1), BC64(sy1), BC64(sx2), BC64(sy2),
-                                   b0, b1, b2, tx0, ty0, tx1, ty1, z0, dz1, dz2, ia, ord);
+                const int64_t a0 = BC(A0), bb0 = BC(B0), a1 = BC(A1), bb1 = BC(B1), a2 = BC(A2), bb2 = BC(B2);
+                sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), a0 * 256, bb0 * 256, a1 * 256, bb1 * 256, a2 * 256, bb2 * 256,
+                                   b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
             }
 #undef BC64
 #undef BC
         }
-        VR_PROF_MARK(3);
+        VR_PROF_MARK(4);
     }
     __syncthreads();
-    VR_PROF_MARK(4);
+    VR_PROF_MARK(5);
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
     const bool vec_ok = (a.w & 3) == 0;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quad, (short)0, (int)hm.quad_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.base, (short)0, (int)al.chain_bytes, 0x00020000);
     for (int g = tid; g < TILE * TILE / 4; g += 256) {
         const int ly = g / (TILE / 4), lx0 = (g % (TILE / 4)) * 4;
         const int gy = oy + ly, gx0 = ox + lx0;
@@ -888,7 +1007,15 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         uint32_t covered = 0;
         float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
         uint32_t prev = 0xffffffffu;
-        ScreenVert s0, s1, s2; TriSetup t; TriDeriv td;
+        // the winner's record (groups 1, 2, 5..8).  The two edge functions that give the barycentrics are stepped in
+        // double precision: every term is an integer below 2^52 (|A|, |B| < 2^23, |P - vertex| < 2^28), so the arithmetic is exact
+        // and v_cvt_f32_f64 rounds the exact edge value once - the same float as (float)(int64) - in 2 instructions per
+        // edge and pixel for triangles of any size.  Giants beyond that (clipped at the guard band) take the int64 path.
+        const uint4* __restrict__ rp = recs;
+        bool dok = true;
+        double d1 = 0.0, d2 = 0.0, sx1 = 0.0, sx2 = 0.0;
+        float ia = 0.0f, iw0 = 0.0f, iw1 = 0.0f, iw2 = 0.0f, wx0 = 0.0f, wx1 = 0.0f, wx2 = 0.0f, wz0 = 0.0f, wz1 = 0.0f, wz2 = 0.0f;
+        float ddenx = 0.0f, ddeny = 0.0f, nxx = 0.0f, nzx = 0.0f, nxy = 0.0f, nzy = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = vis[ly * TILE + lx0 + k];
@@ -898,17 +1025,43 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             covered |= 1u << k;
             if (a.depth_only) continue;
             if (low != prev) {                                    // neighbours usually share the triangle
-                uint32_t i0, i1, i2;
-                entry_vertices(key_of(low), hard_tris, hard_first, i0, i1, i2);
-                s0 = load_sv(verts, i0); s1 = load_sv(verts, i1); s2 = load_sv(verts, i2);
-                t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, WIRE);
-                td = tri_derivs(t);
+                rp = recs + rec_index(key_of(low), hard_first, rec_hard_base) * kRecGroups;
+                const uint4 g1 = rp[1], g2 = rp[2], g5 = rp[5], g6 = rp[6], g7 = rp[7], g8 = rp[8];
+                const int32_t A1 = (int32_t)g1.x, B1 = (int32_t)g1.y, A2 = (int32_t)g2.x, B2 = (int32_t)g2.y;
+                dok = max(max(abs(A1), abs(B1)), max(abs(A2), abs(B2))) < (1 << 23);
+                // edge values at the group's first pixel, exact in int64, then as doubles
+                const int32_t PXg = (gx0) * 256 + 128, PYg = gy * 256 + 128;
+                d1 = (double)edge_eval(A1, B1, rec_c(g1), PXg, PYg); d2 = (double)edge_eval(A2, B2, rec_c(g2), PXg, PYg);
+                sx1 = (double)A1 * 256.0; sx2 = (double)A2 * 256.0;
+                iw0 = __uint_as_float(g5.x); iw1 = __uint_as_float(g5.y); iw2 = __uint_as_float(g5.z); ddenx = __uint_as_float(g5.w);
+                wx0 = __uint_as_float(g6.x); wx1 = __uint_as_float(g6.y); wx2 = __uint_as_float(g6.z); ddeny = __uint_as_float(g6.w);
+                wz0 = __uint_as_float(g7.x); wz1 = __uint_as_float(g7.y); wz2 = __uint_as_float(g7.z); ia = __uint_as_float(g7.w);
+                nxx = __uint_as_float(g8.x); nzx = __uint_as_float(g8.y); nxy = __uint_as_float(g8.z); nzy = __uint_as_float(g8.w);
                 prev = low;
             }
-            const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
-            const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
-            const Attr p = interp_attr(s0, s1, s2, t.inv_area, td, E1, E2);
-            pixel_shader(a, hm, al, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
+            float fe1, fe2;
+            if (dok) { fe1 = (float)__builtin_fma(sx1, (double)k, d1); fe2 = (float)__builtin_fma(sx2, (double)k, d2); }
+            else {
+                const uint4 g1 = rp[1], g2 = rp[2];
+                const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
+                fe1 = (float)edge_eval((int32_t)g1.x, (int32_t)g1.y, rec_c(g1), PX, PY);
+                fe2 = (float)edge_eval((int32_t)g2.x, (int32_t)g2.y, rec_c(g2), PX, PY);
+            }
+            // perspective-correct world xz and its screen-space derivatives (terrain_ps.hlsl interpolants)
+            Attr p;
+            {
+                const float l1 = fe1 * ia, l2 = fe2 * ia;
+                const float l0 = (1.0f - l1) - l2;
+                const float q0 = l0 * iw0, q1 = l1 * iw1, q2 = l2 * iw2;
+                const float den = (q0 + q1) + q2;
+                const float r = 1.0f / den;
+                const float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
+                p.wx = (b0 * wx0 + b1 * wx1) + b2 * wx2;
+                p.wz = (b0 * wz0 + b1 * wz1) + b2 * wz2;
+                p.dwxdx = (nxx - p.wx * ddenx) * r; p.dwzdx = (nzx - p.wz * ddenx) * r;
+                p.dwxdy = (nxy - p.wx * ddeny) * r; p.dwzdy = (nzy - p.wz * ddeny) * r;
+            }
+            pixel_shader(a, hm, al, rq, rc, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);
@@ -951,7 +1104,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             }
         }
     }
-    VR_PROF_MARK(5);
+    VR_PROF_MARK(6);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1037,9 +1190,10 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     { VrKernelScope ks(ctx, VR_K_VERTEX, gs);
     hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, gs, va, t->height, g.d_instances, g.d_counters, g.d_verts); }
     { VrKernelScope ks(ctx, VR_K_SETUP, gs);
-    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count); }
+    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count, g.d_recs); }
     { VrKernelScope ks(ctx, VR_K_CLIP, gs);
-    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count); }
+    hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count,
+                       g.d_recs + (size_t)t->p.max_instances * kTrisPerInst * kRecGroups); }
     { VrKernelScope ks(ctx, VR_K_SCAN, gs);
     const bool whole = pt == nullptr;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity,
@@ -1120,7 +1274,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32> : k_raster<false, 32>)
                                       : (a.wireframe ? k_raster<true, 64> : k_raster<false, 64>);
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
-                           g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
+                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
     }
     VR_HIP(hipEventRecord(g.ev_raster_done, s));

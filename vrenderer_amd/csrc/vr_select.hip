@@ -451,6 +451,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
         VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
         VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
+        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * 9 * sizeof(uint4));
         VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
         VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
         VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
@@ -487,7 +488,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
         (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
-        (void)hipFree(g.d_rect); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
+        (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
         (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
     }
     (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights); (void)hipFree(t->d_minmax);

@@ -76,11 +76,16 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         total = (total + 255) / 256 * 256;
         quad_off = total; total += quad_dwords * sizeof(uint32_t);
     }
+    VR_REQUIRE(total < ((size_t)1 << 31), "texture too large");        // texels are addressed with 32-bit byte offsets
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
     hipStream_t s = ctx->stream;
-    VR_HIP(hipMemcpyAsync(mem, host, (size_t)w * h * tb, hipMemcpyHostToDevice, s));
-    VR_HIP(hipMemcpyAsync(mem + table_off, off, sizeof(off), hipMemcpyHostToDevice, s));
+    // on any failure below: wait for the copies that read this function's stack arrays, free, report
+#define VR_TEX_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipStreamSynchronize(s); (void)hipFree(mem); \
+        vr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+        return e_ == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP; } } while (0)
+    VR_TEX_TRY(hipMemcpyAsync(mem, host, (size_t)w * h * tb, hipMemcpyHostToDevice, s));
+    VR_TEX_TRY(hipMemcpyAsync(mem + table_off, off, sizeof(off), hipMemcpyHostToDevice, s));
     int sw = w, sh = h;
     for (int l = 1; l < levels; l++) {
         int dw = sw > 1 ? sw >> 1 : 1, dh = sh > 1 ? sh >> 1 : 1;
@@ -92,7 +97,7 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
     }
     out->quad = nullptr; out->qoff = nullptr;
     if (tb == 1) {
-        VR_HIP(hipMemcpyAsync(mem + qtable_off, qoff, sizeof(qoff), hipMemcpyHostToDevice, s));
+        VR_TEX_TRY(hipMemcpyAsync(mem + qtable_off, qoff, sizeof(qoff), hipMemcpyHostToDevice, s));
         for (int l = 0; l < levels; l++) {
             int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
             dim3 blk(32, 8), grd((lw + 2 + 31) / 32, (lh + 2 + 7) / 8);
@@ -100,9 +105,11 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         }
         out->quad = (const uint32_t*)(mem + quad_off); out->qoff = (const uint32_t*)(mem + qtable_off);
     }
-    VR_HIP(hipGetLastError());
-    VR_HIP(hipStreamSynchronize(s));   // host source buffer is caller-owned: finish the copy before returning
-    out->base = mem; out->off = (const uint32_t*)(mem + table_off); out->levels = levels; out->w0 = w; out->h0 = h; out->pad = 0;
+    VR_TEX_TRY(hipGetLastError());
+    VR_TEX_TRY(hipStreamSynchronize(s));   // host source buffer is caller-owned: finish the copy before returning
+#undef VR_TEX_TRY
+    out->base = mem; out->off = (const uint32_t*)(mem + table_off); out->levels = levels; out->w0 = w; out->h0 = h;
+    out->chain_bytes = (uint32_t)table_off; out->quad_bytes = (uint32_t)(quad_dwords * sizeof(uint32_t)); out->pad = 0;
     *out_mem = mem;
     return VR_OK;
 }
@@ -201,9 +208,10 @@ extern "C" VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t se
 __global__ void k_debug_srgb_encode(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out, const float* __restrict__ thr_g,
                                     const uint8_t* __restrict__ tab_g)
 {
-    __shared__ float thr[256];
+    __shared__ float thr[kThrTabSize];
     __shared__ uint8_t tab[kEncTabSize];
     thr[threadIdx.x] = thr_g[threadIdx.x];
+    if (threadIdx.x == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     for (int i = threadIdx.x; i < kEncTabSize; i += blockDim.x) tab[i] = tab_g[i];
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -147,16 +147,17 @@ __device__ __forceinline__ uint32_t vr_srgb_encode(float x, const float* thr)
 
 // Same result as vr_srgb_encode (the largest k with thr[k] <= x) without the 8-step search: the
 // float's exponent and top 7 mantissa bits select a bucket whose smallest value has code tab[b]
-// (host-built from the same thresholds); a bucket spans at most ~0.6 codes, so one comparison
-// against the next threshold (a loop, for safety) finishes it.  tab / thr live in LDS.
+// (host-built from the same thresholds).  A bucket spans less than one code (at most 0.875 of one, at x -> 1),
+// so it holds at most one threshold - vr_context_create verifies that for every bucket - and ONE comparison
+// against the next threshold finishes the job.  tab / thr live in LDS; thr has 257 entries, thr[256] = NaN (never <= x).
+constexpr int kThrTabSize = 257;
 __device__ __forceinline__ uint32_t vr_srgb_encode_fast(float x, const float* __restrict__ thr, const uint8_t* __restrict__ tab)
 {
-    if (!(x > 0.0f)) return 0u;                                    // zero (either sign), negatives and NaN
     int b = (int)(__float_as_uint(x) >> 16) - kEncTabBase;
     b = b < 0 ? 0 : (b > kEncTabSize - 1 ? kEncTabSize - 1 : b);   // below 2^-13 -> code 0, >= 1 -> 255
-    uint32_t g = tab[b];
-    while (g < 255u && x >= thr[g + 1u]) g++;
-    return g;
+    const uint32_t g = tab[b];
+    const uint32_t code = g + (x >= thr[g + 1u] ? 1u : 0u);
+    return x > 0.0f ? code : 0u;                                   // zero (either sign), negatives and NaN
 }
 
 __device__ __forceinline__ uint32_t vr_snorm16(float v)

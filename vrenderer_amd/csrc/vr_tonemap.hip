@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256) void k_tonemap(TmArgs a, const void* __restric
                                                   const float* __restrict__ exposure, void* __restrict__ dst,
                                                   const float* __restrict__ thr_g, const uint8_t* __restrict__ enc_g)
 {
-    __shared__ float thr[256];
+    __shared__ float thr[kThrTabSize];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     thr[threadIdx.x] = thr_g[threadIdx.x];
+    if (threadIdx.x == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     for (int i = threadIdx.x; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     __syncthreads();
     const QuadPos q = quad_pos<PACKED>(a, owned_tiles, blockIdx.x, (int)threadIdx.x);
@@ -266,9 +267,10 @@ __global__ __launch_bounds__(256) void k_tonemap_scalar(TmArgs a, const uint2* _
                                                          uint32_t* __restrict__ dst, const float* __restrict__ thr_g,
                                                          const uint8_t* __restrict__ enc_g)
 {
-    __shared__ float thr[256];
+    __shared__ float thr[kThrTabSize];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     thr[threadIdx.x] = thr_g[threadIdx.x];
+    if (threadIdx.x == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     for (int i = threadIdx.x; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     __syncthreads();
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
