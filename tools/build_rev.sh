@@ -1,0 +1,13 @@
+#!/bin/bash
+# Scratch: build libvrterrain.so of git revision $1 into vrenderer_amd/lib/variants/$2/ (for same-box A/B timing)
+set -e
+REV=$1; NAME=$2
+T=$(mktemp -d)
+mkdir -p $T/vrenderer_amd/csrc $T/include vrenderer_amd/lib/variants/$NAME
+for f in $(git ls-tree --name-only $REV vrenderer_amd/csrc/); do git show $REV:$f > $T/$f; done
+git show $REV:include/vrterrain.h > $T/include/vrterrain.h
+cd $T/vrenderer_amd/csrc
+for f in *.hip; do /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden -c $f -o $T/${f%.hip}.o & done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/vrenderer_amd/lib/variants/$NAME/libvrterrain.so $T/*.o
+rm -rf $T
+echo built $NAME from $REV

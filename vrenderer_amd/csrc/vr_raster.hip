@@ -618,12 +618,73 @@ __device__ __forceinline__ void srgb_filter(uint32_t p00, uint32_t p10, uint32_t
     }
 }
 
+// One axis of a bilinear footprint: texel-space coordinate -> integer floor (clamped to [-1, n], as the quad table is
+// indexed) and fraction.  Same operations as quad_tap / vr_bilinear_setup, once per distinct coordinate.
+struct Axis { int i; float f; };
+__device__ __forceinline__ Axis tap_axis(int n, float t)
+{
+    const float x = t * (float)n - 0.5f;
+    float xf = floorf(x);
+    Axis r; r.f = x - xf;
+    xf = vr_min(vr_max(xf, -1.0f), (float)n);
+    r.i = (int)xf;
+    return r;
+}
+__device__ __forceinline__ float quad_filter_f(uint32_t e, float fx, float fy, const float* __restrict__ r8)
+{
+    const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
+    const float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
+    return top + (bot - top) * fy;
+}
+// NaN never reaches the normal's encode (the vector is normalised from a length >= 0.2): clamp, scale, round half away
+__device__ __forceinline__ uint32_t snorm16_finite(float v)
+{
+    const float s = vr_min(vr_max(v, -1.0f), 1.0f) * 32767.0f;
+    return (uint32_t)(int)(s + copysignf(0.5f, s)) & 0xffffu;      // == (s >= 0 ? s + 0.5 : s - 0.5) for every finite s
+}
+
+// One mip level of main_ps's five taps (terrain_ps.hlsl:59-61, :68): four height taps at uv +- 0.1 through the quad
+// table and the albedo footprint at uv.  SAME: heightmap and albedo have the same size (the reference's case), so the
+// albedo footprint is the floor / fraction pair the height taps at the unshifted u and v already computed.
+template <bool SAME>
+__device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc,
+                                             const float* __restrict__ lut, const float* __restrict__ r8, const uint32_t* __restrict__ qoff,
+                                             const uint32_t* __restrict__ aoff, int lvl_h, int lvl_c, float ua, float ub, float va, float vb,
+                                             float u0, float v0, float u, float v, float hgt[4], float col[3])
+{
+    const int w = max(1, hm.w0 >> lvl_h), h = max(1, hm.h0 >> lvl_h);
+    const uint32_t q = qoff[lvl_h], c = aoff[lvl_c];             // dword offset of the quad table, byte offset of the albedo level
+    const Axis xa = tap_axis(w, ua), xb = tap_axis(w, ub), x0 = tap_axis(w, u0), y0 = tap_axis(h, v0), ya = tap_axis(h, va), yb = tap_axis(h, vb);
+    const int r0 = __mul24(y0.i + 1, w + 2) + 1, ra = __mul24(ya.i + 1, w + 2) + 1, rb = __mul24(yb.i + 1, w + 2) + 1;
+#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b32(rq, (q + (uint32_t)(i)) << 2, 0, 0)
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
+    const uint32_t e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
+    uint32_t p00, p10, p01, p11; float cfx, cfy;
+    if (SAME) {
+        const int cx0 = vr_clampi(x0.i, 0, w - 1), cx1 = vr_clampi(x0.i + 1, 0, w - 1), cy0 = vr_clampi(y0.i, 0, h - 1), cy1 = vr_clampi(y0.i + 1, 0, h - 1);
+        const int q0 = __mul24(cy0, w), q1 = __mul24(cy1, w);
+        p00 = LDC(q0 + cx0); p10 = LDC(q0 + cx1); p01 = LDC(q1 + cx0); p11 = LDC(q1 + cx1);
+        cfx = x0.f; cfy = y0.f;
+    } else {
+        const BilinearSetup s = vr_bilinear_setup(max(1, al.w0 >> lvl_c), max(1, al.h0 >> lvl_c), u, v);
+        p00 = LDC(s.i00); p10 = LDC(s.i10); p01 = LDC(s.i01); p11 = LDC(s.i11);
+        cfx = s.fx; cfy = s.fy;
+    }
+#undef LDQ
+#undef LDC
+    hgt[0] = quad_filter_f(e0, xa.f, y0.f, r8); hgt[1] = quad_filter_f(e1, xb.f, y0.f, r8);
+    hgt[2] = quad_filter_f(e2, x0.f, ya.f, r8); hgt[3] = quad_filter_f(e3, x0.f, yb.f, r8);
+    BilinearSetup fs; fs.fx = cfx; fs.fy = cfy; fs.i00 = fs.i10 = fs.i01 = fs.i11 = 0;
+    srgb_filter(p00, p10, p01, p11, fs, lut, col);
+}
+
 // main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels.  qoff / aoff: LDS copies of the
 // per-level offset tables (no dependent global load in front of a texel fetch).  The finer level of
 // the four height taps and of the albedo tap is fetched as one batch of 8 loads; the coarser level
 // (only when a LOD fraction is non-zero) as a second batch.
 // Texels are fetched through buffer resources (rq: the quad tables, rc: the albedo chain): a fetch's address is one
 // 32-bit byte offset (1 VALU) instead of a 64-bit pointer sum (3), and an out-of-range offset reads 0 instead of faulting.
+template <bool SAME>
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq,
                                              __amdgpu_buffer_rsrc_t rc, const float* __restrict__ lut,
                                              const float* __restrict__ thr, const uint8_t* __restrict__ enc, const float* __restrict__ r8,
@@ -633,41 +694,26 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     const float u = to_uv(a, p.wx), v = to_uv(a, p.wz);                                      // :12-13, :20-21
     const float dudx = div_ws(a, p.dwxdx), dvdx = div_ws(a, p.dwzdx), dudy = div_ws(a, p.dwxdy), dvdy = div_ws(a, p.dwzdy);
     const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
-    const float lod_c = (hm.w0 == al.w0 && hm.h0 == al.h0) ? lod_h : vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0);
-    const LodSplit lh = vr_lod_split(hm.levels, lod_h), lc = vr_lod_split(al.levels, lod_c);
+    const LodSplit lh = vr_lod_split(hm.levels, lod_h);
+    LodSplit lc = lh;                                            // same size and level count: the same LOD
+    if (!SAME) lc = vr_lod_split(al.levels, vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0));
     const float offset = 0.1f;                                                              // :59
     const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset), u0 = u + 0.0f, v0 = v + 0.0f;
     float hgt[4], col[3];
-    {
-        const int w = max(1, hm.w0 >> lh.l0), h = max(1, hm.h0 >> lh.l0), wc = max(1, al.w0 >> lc.l0), hc = max(1, al.h0 >> lc.l0);
-        const uint32_t q = qoff[lh.l0], c = aoff[lc.l0];        // dword offset of the quad table, byte offset of the albedo level
-        const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
-        const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
-#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b32(rq, (q + (i)) << 2, 0, 0)
-#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
-        const uint32_t e0 = LDQ(t0.idx), e1 = LDQ(t1.idx), e2 = LDQ(t2.idx), e3 = LDQ(t3.idx);
-        const uint32_t p00 = LDC(s.i00), p10 = LDC(s.i10), p01 = LDC(s.i01), p11 = LDC(s.i11);
-        hgt[0] = quad_filter(e0, t0, r8); hgt[1] = quad_filter(e1, t1, r8); hgt[2] = quad_filter(e2, t2, r8); hgt[3] = quad_filter(e3, t3, r8);
-        srgb_filter(p00, p10, p01, p11, s, lut, col);
-    }
+    sample_level<SAME>(hm, al, rq, rc, lut, r8, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
     if (__any(lh.f > 0.0f || lc.f > 0.0f)) {
         // blending with a zero fraction returns the finer sample exactly, so one branch serves both textures
         const int l1h = min(lh.l0 + 1, hm.levels - 1), l1c = min(lc.l0 + 1, al.levels - 1);
-        const int w = max(1, hm.w0 >> l1h), h = max(1, hm.h0 >> l1h), wc = max(1, al.w0 >> l1c), hc = max(1, al.h0 >> l1c);
-        const uint32_t q = qoff[l1h], c = aoff[l1c];
-        const QuadTap t0 = quad_tap(w, h, ua, v0), t1 = quad_tap(w, h, ub, v0), t2 = quad_tap(w, h, u0, va), t3 = quad_tap(w, h, u0, vb);
-        const BilinearSetup s = vr_bilinear_setup(wc, hc, u, v);
-        const uint32_t e0 = LDQ(t0.idx), e1 = LDQ(t1.idx), e2 = LDQ(t2.idx), e3 = LDQ(t3.idx);
-        const uint32_t p00 = LDC(s.i00), p10 = LDC(s.i10), p01 = LDC(s.i01), p11 = LDC(s.i11);
-#undef LDQ
-#undef LDC
-        const float g0 = quad_filter(e0, t0, r8), g1 = quad_filter(e1, t1, r8), g2 = quad_filter(e2, t2, r8), g3 = quad_filter(e3, t3, r8);
-        float cb[3];
-        srgb_filter(p00, p10, p01, p11, s, lut, cb);
-        hgt[0] = hgt[0] + (g0 - hgt[0]) * lh.f; hgt[1] = hgt[1] + (g1 - hgt[1]) * lh.f;
-        hgt[2] = hgt[2] + (g2 - hgt[2]) * lh.f; hgt[3] = hgt[3] + (g3 - hgt[3]) * lh.f;
+        // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
+        // (its loads and arithmetic are speculatable; left alone the compiler may run both levels for every pixel).
+        float xa = ua, xb = ub, ya = va, yb = vb, x0 = u0, y0 = v0, xu = u, yv = v;
+        asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ya), "+v"(yb), "+v"(x0), "+v"(y0), "+v"(xu), "+v"(yv));
+        float g[4], cb[3];
+        sample_level<SAME>(hm, al, rq, rc, lut, r8, qoff, aoff, l1h, l1c, xa, xb, ya, yb, x0, y0, xu, yv, g, cb);
+        hgt[0] = hgt[0] + (g[0] - hgt[0]) * lh.f; hgt[1] = hgt[1] + (g[1] - hgt[1]) * lh.f;
+        hgt[2] = hgt[2] + (g[2] - hgt[2]) * lh.f; hgt[3] = hgt[3] + (g[3] - hgt[3]) * lh.f;
 #pragma unroll
         for (int k = 0; k < 3; k++) col[k] = col[k] + (cb[k] - col[k]) * lc.f;
     }
@@ -677,8 +723,8 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     nx *= inv; ny *= inv; nz *= inv;
     diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
-    n01 = vr_snorm16(nx) | (vr_snorm16(ny) << 16);                                          // :78
-    n23 = vr_snorm16(nz) | (32767u << 16);                                                  // :79 roughness = 1
+    n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
+    n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
 }
 
 // Low half of a visibility-buffer word: ~(key + 1), so a later bin entry (larger key) gives a SMALLER word and
@@ -814,7 +860,7 @@ extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
 #define VR_PROF_ADD(i, v) do { } while (0)
 #endif
 
-template <bool WIRE, int TILE>
+template <bool WIRE, int TILE, bool SAME>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
@@ -842,6 +888,11 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
+    if (a.assume_cleared && ox + TILE <= a.w && oy + TILE <= a.h) {       // interior tile of a cleared target: one constant
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 cv = { 0x3f800000ffffffffull, 0x3f800000ffffffffull };
+        for (int i = tid; i < TILE * TILE / 2; i += 256) reinterpret_cast<u64x2*>(vis)[i] = cv;
+    } else
     for (int i = tid; i < TILE * TILE; i += 256) {
         const int lx = i & (TILE - 1), ly = i / TILE;
         const int gx = ox + lx, gy = oy + ly;
@@ -1061,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 p.dwxdx = (nxx - p.wx * ddenx) * r; p.dwzdx = (nzx - p.wz * ddenx) * r;
                 p.dwxdy = (nxy - p.wx * ddeny) * r; p.dwzdy = (nzy - p.wz * ddeny) * r;
             }
-            pixel_shader(a, hm, al, rq, rc, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
+            pixel_shader<SAME>(a, hm, al, rq, rc, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
         const size_t pix = (size_t)gy * a.w + gx0;
         const int npx = min(4, a.w - gx0);
@@ -1271,8 +1322,10 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER, s, true);
         const int32_t* tiles = g.d_tile_order;            // this frame's tiles, longest bins first (k_scan)
-        auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32> : k_raster<false, 32>)
-                                      : (a.wireframe ? k_raster<true, 64> : k_raster<false, 64>);
+        // heightmap and albedo of one size (the reference's case): the albedo footprint shares the height taps' coordinates
+        const bool same = t->height.w0 == t->albedo.w0 && t->height.h0 == t->albedo.h0 && t->height.levels == t->albedo.levels;
+        auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32, false> : (same ? k_raster<false, 32, true> : k_raster<false, 32, false>))
+                                      : (a.wireframe ? k_raster<true, 64, false> : (same ? k_raster<false, 64, true> : k_raster<false, 64, false>));
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
