@@ -253,13 +253,20 @@ VR_API int  vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* 
                               const float ambient_top[3], const float ambient_bottom[3],
                               vr_image* hdr_out, const vr_partition* part);
 
-/* The same pass for many lights (BASELINE config 5: 1024 point lights): per 16x16 screen tile the
+/* The same pass for many lights (BASELINE config 5: 1024 point lights): per 32x32 screen tile the
  * lights are culled against the tile's world-space bounds into an LDS list, then every pixel
- * shades only that list.  Same inputs/outputs as vr_deferred_light; any number of lights. */
+ * shades only that list.  Same inputs/outputs as vr_deferred_light; up to 65536 lights in all and
+ * VR_TILE_LIGHT_CAP lights per tile after culling.  A tile that keeps more drops the excess (in
+ * light order) and raises a device-side flag; the launch stays asynchronous, so the condition is
+ * reported by vr_deferred_tiled_status. */
+#define VR_TILE_LIGHT_CAP 1024
 VR_API int  vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb,
                                     const vr_light* lights, int32_t num_lights,
                                     const float ambient_top[3], const float ambient_bottom[3],
                                     vr_image* hdr_out, const vr_partition* part);
+/* Waits for the tiled passes queued so far on this context and returns VR_ERR_OVERFLOW if any of their
+ * tiles kept more than VR_TILE_LIGHT_CAP lights since the last call (the flag is cleared), else VR_OK. */
+VR_API int  vr_deferred_tiled_status(vr_context* ctx);
 
 /* ---- terrain shadows ---------------------------------------- */
 /* The reference renders the terrain depth-only from the sun into a 2048^2 one-cascade shadow map every
@@ -373,6 +380,9 @@ VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
 VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8]);
 /* test helper: the device's linear -> sRGB8 render-target conversion applied to n host floats */
 VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, size_t n, uint8_t* out);
+/* Test helper: sweeps every float with an exponent in [-60, 60) through the pixel shader's short reciprocal and square-root
+ * sequences and counts differences from 1.0f / x and sqrtf(x): out[0] reciprocal, out[1] square root, out[2] values swept. */
+VR_API int vr_debug_fastmath_check(vr_context* ctx, unsigned long long out[3]);
 
 #ifdef __cplusplus
 }

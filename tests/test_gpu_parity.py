@@ -324,6 +324,16 @@ def test_device_srgb_encode_equals_threshold_search(oracle, gpu_ctx):
     assert bad.size == 0, (bad[:5], x[bad[:5]], got[bad[:5]], want[bad[:5]])
 
 
+def test_short_reciprocal_and_sqrt_equal_ieee(gpu_ctx):
+    """The pixel shader's 1/x and sqrt(x) drop the compiler's out-of-range scaling; inside the range they are used for
+    (|x| in [2^-60, 2^60)) they must equal 1.0f / x and sqrtf(x) for EVERY float: exhaustive sweep on the device."""
+    import ctypes as C
+    out = (C.c_ulonglong * 3)()
+    vr.capi.check(gpu_ctx.lib.vr_debug_fastmath_check(gpu_ctx.handle, out), "vr_debug_fastmath_check")
+    assert out[2] == 120 << 23, out[2]
+    assert out[0] == 0 and out[1] == 0, (out[0], out[1])
+
+
 def _scene_lights(scene, n):
     lights = [vr.reference_sun()] + vr.synthetic_point_lights(n - 1, float(scene["size"]), scene["h"], 400.0, seed=9001)
     for l in lights[1:]:                      # ranges authored for the 2048 world; scale to this scene

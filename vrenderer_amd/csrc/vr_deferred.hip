@@ -464,7 +464,7 @@ extern "C" VR_API int vr_deferred_light_shadowed(vr_context* ctx, const vr_view*
 // A light culled here has zero attenuation for every pixel of the tile, so the sum equals the
 // all-lights loop of the oracle.
 constexpr int kLightTile = 32;
-constexpr int kTileLightCap = 1024;
+constexpr int kTileLightCap = VR_TILE_LIGHT_CAP;
 // 32 B per staged light (4 workgroups of 1024 lights fit a CU's LDS): colour premultiplied by the intensity;
 // w = 0 for a point light, 1 + half angular size for a directional one (its cos/sin/tan are then taken per pixel).
 struct TiledLight { float vec[3]; float inv_range; float color[3]; float w; };
@@ -665,6 +665,22 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
                            (const int32_t*)nullptr, ctx->d_flags);
     }
     VR_HIP(hipGetLastError());
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_deferred_tiled_status(vr_context* ctx)
+{
+    VR_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (!ctx->d_flags) return VR_OK;                         // no tiled pass has run on this context
+    VR_HIP(hipSetDevice(ctx->device));
+    uint32_t flags = 0;
+    VR_HIP(hipMemcpyAsync(&flags, ctx->d_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(flags), ctx->stream));
+    VR_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags & 1u) {
+        vr_set_error("vr_deferred_light_tiled: a 32x32 tile kept more than %d lights; the excess was dropped", kTileLightCap);
+        return VR_ERR_OVERFLOW;
+    }
     return VR_OK;
 }
 

@@ -56,6 +56,12 @@ struct DevTex {
     const uint32_t* quad;
     const uint32_t* qoff;       // device table: dword offset of each level's quad table
     uint32_t quad_bytes, pad;   // bytes of all quad tables at `quad`
+    // The same footprints decoded: per entry (t00, t10 - t00, t01, t11 - t01) as floats (t = byte / 255), same indexing.
+    // A height tap is then one 16-byte load and 7 float operations - no byte extraction, no conversion table.
+    const float4* quadf;
+    // SRGBA8 textures only: the chain decoded to linear floats, 3 per texel (12 B); level l starts at float 3 * off[l] / 4.
+    // An albedo texel is then one 12-byte load with nothing to extract or look up.
+    const float* rgbf;
 };
 
 // Per-light constants the deferred kernel reads (host precomputes the half-angle terms).
@@ -210,6 +216,32 @@ int vr_partition_slot_tables(vr_context* ctx, int w, int h, int world, const Par
 // ---- device helpers shared by kernels ---------------------------------------------------
 __device__ __forceinline__ float vr_max(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float vr_min(float a, float b) { return a < b ? a : b; }
+// x clamped to [lo, hi] in one instruction (v_med3_f32); x must not be NaN
+__device__ __forceinline__ float vr_clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// 1 / d and sqrt(x), correctly rounded, for operands well inside the normal range (2^-60 < |d|, x < 2^60): the compiler's
+// own IEEE sequences without the range scaling (v_div_scale / v_div_fixup, the 2^32 pre-scale of small roots) that
+// only matters outside it; results are bit-identical to 1.0f / d and sqrtf(x) there (vr_debug_fastmath_check sweeps
+// every float of the range).  Saves 4 and 9 instructions per call in the tile pass's pixel shader.
+__device__ __forceinline__ float vr_rcp_exact(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;                                         // 1 * r
+    float rem = __builtin_fmaf(-d, q, 1.0f);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(rem, r, q);
+}
+__device__ __forceinline__ float vr_sqrt_exact(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
+    float r = vp <= 0.0f ? dn : s;
+    r = vs > 0.0f ? up : r;
+    return r;
+}
 __device__ __forceinline__ float vr_saturate(float x) { return vr_min(vr_max(x, 0.0f), 1.0f); }
 __device__ __forceinline__ float vr_dot3(float ax, float ay, float az, float bx, float by, float bz)
 {

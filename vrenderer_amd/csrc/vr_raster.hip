@@ -626,8 +626,7 @@ __device__ __forceinline__ Axis tap_axis(int n, float t)
     const float x = t * (float)n - 0.5f;
     float xf = floorf(x);
     Axis r; r.f = x - xf;
-    xf = vr_min(vr_max(xf, -1.0f), (float)n);
-    r.i = (int)xf;
+    r.i = (int)vr_clampf(xf, -1.0f, (float)n);
     return r;
 }
 __device__ __forceinline__ float quad_filter_f(uint32_t e, float fx, float fy, const float* __restrict__ r8)
@@ -639,7 +638,7 @@ __device__ __forceinline__ float quad_filter_f(uint32_t e, float fx, float fy, c
 // NaN never reaches the normal's encode (the vector is normalised from a length >= 0.2): clamp, scale, round half away
 __device__ __forceinline__ uint32_t snorm16_finite(float v)
 {
-    const float s = vr_min(vr_max(v, -1.0f), 1.0f) * 32767.0f;
+    const float s = vr_clampf(v, -1.0f, 1.0f) * 32767.0f;
     return (uint32_t)(int)(s + copysignf(0.5f, s)) & 0xffffu;      // == (s >= 0 ? s + 0.5 : s - 0.5) for every finite s
 }
 
@@ -656,10 +655,24 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     const uint32_t q = qoff[lvl_h], c = aoff[lvl_c];             // dword offset of the quad table, byte offset of the albedo level
     const Axis xa = tap_axis(w, ua), xb = tap_axis(w, ub), x0 = tap_axis(w, u0), y0 = tap_axis(h, v0), ya = tap_axis(h, va), yb = tap_axis(h, vb);
     const int r0 = __mul24(y0.i + 1, w + 2) + 1, ra = __mul24(ya.i + 1, w + 2) + 1, rb = __mul24(yb.i + 1, w + 2) + 1;
+#ifdef VR_QUAD_U8
 #define LDQ(i) __builtin_amdgcn_raw_buffer_load_b32(rq, (q + (uint32_t)(i)) << 2, 0, 0)
-#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
     const uint32_t e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
-    uint32_t p00, p10, p01, p11; float cfx, cfy;
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, (q + (uint32_t)(i)) << 4, 0, 0)
+    const u32x4 e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
+#endif
+#ifdef VR_ALBEDO_U8
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
+    uint32_t p00, p10, p01, p11;
+#else
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const uint32_t c3 = c * 3u;                                   // the decoded chain: 12 B per texel, levels at 3 x the byte offset
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b96(rc, ((((uint32_t)(i) << 1) + (uint32_t)(i)) << 2) + c3, 0, 0)    // 12 * i + c3, 2 VALU, any texture size
+    u32x3 p00, p10, p01, p11;
+#endif
+    float cfx, cfy;
     if (SAME) {
         const int cx0 = vr_clampi(x0.i, 0, w - 1), cx1 = vr_clampi(x0.i + 1, 0, w - 1), cy0 = vr_clampi(y0.i, 0, h - 1), cy1 = vr_clampi(y0.i + 1, 0, h - 1);
         const int q0 = __mul24(cy0, w), q1 = __mul24(cy1, w);
@@ -672,10 +685,27 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     }
 #undef LDQ
 #undef LDC
+#ifdef VR_QUAD_U8
     hgt[0] = quad_filter_f(e0, xa.f, y0.f, r8); hgt[1] = quad_filter_f(e1, xb.f, y0.f, r8);
     hgt[2] = quad_filter_f(e2, x0.f, ya.f, r8); hgt[3] = quad_filter_f(e3, x0.f, yb.f, r8);
+#else
+    // entry = (t00, t10 - t00, t01, t11 - t01): top = t00 + (t10 - t00) * fx, bot likewise, then across y
+#define QF(e, fx, fy) ({ const float top_ = __uint_as_float((e).x) + __uint_as_float((e).y) * (fx), bot_ = __uint_as_float((e).z) + __uint_as_float((e).w) * (fx); \
+                         top_ + (bot_ - top_) * (fy); })
+    hgt[0] = QF(e0, xa.f, y0.f); hgt[1] = QF(e1, xb.f, y0.f); hgt[2] = QF(e2, x0.f, ya.f); hgt[3] = QF(e3, x0.f, yb.f);
+#undef QF
+#endif
+#ifdef VR_ALBEDO_U8
     BilinearSetup fs; fs.fx = cfx; fs.fy = cfy; fs.i00 = fs.i10 = fs.i01 = fs.i11 = 0;
     srgb_filter(p00, p10, p01, p11, fs, lut, col);
+#else
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t00 = __uint_as_float(p00[k]), t10 = __uint_as_float(p10[k]), t01 = __uint_as_float(p01[k]), t11 = __uint_as_float(p11[k]);
+        const float top = t00 + (t10 - t00) * cfx, bot = t01 + (t11 - t01) * cfx;
+        col[k] = top + (bot - top) * cfy;
+    }
+#endif
 }
 
 // main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels.  qoff / aoff: LDS copies of the
@@ -719,7 +749,7 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     }
     const float hDx = hgt[0] - hgt[1], hDy = hgt[2] - hgt[3];                                // :60-61
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
-    const float inv = 1.0f / sqrtf(vr_dot3(nx, ny, nz, nx, ny, nz));
+    const float inv = vr_rcp_exact(vr_sqrt_exact(vr_dot3(nx, ny, nz, nx, ny, nz)));         // 1.0f / sqrtf(.), length in [0.2, 1.43]
     nx *= inv; ny *= inv; nz *= inv;
     diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
@@ -1049,8 +1079,16 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
     const bool vec_ok = (a.w & 3) == 0;
+#ifdef VR_QUAD_U8
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quad, (short)0, (int)hm.quad_bytes, 0x00020000);
+#else
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
+#endif
+#ifdef VR_ALBEDO_U8
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.base, (short)0, (int)al.chain_bytes, 0x00020000);
+#else
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 3u), 0x00020000);
+#endif
     for (int g = tid; g < TILE * TILE / 4; g += 256) {
         const int ly = g / (TILE / 4), lx0 = (g % (TILE / 4)) * 4;
         const int gy = oy + ly, gx0 = ox + lx0;
@@ -1105,7 +1143,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 const float l0 = (1.0f - l1) - l2;
                 const float q0 = l0 * iw0, q1 = l1 * iw1, q2 = l2 * iw2;
                 const float den = (q0 + q1) + q2;
-                const float r = 1.0f / den;
+                // 1.0f / den: den = the interpolated 1/w of a point in front of the near plane, far inside the safe range;
+                // anything else (a wire pixel far off its triangle's plane) takes the general division
+                const float aden = fabsf(den);
+                float r;
+                if (__any(!(aden > 0x1p-60f && aden < 0x1p60f))) r = 1.0f / den;       // (wave-uniform, practically never taken)
+                else r = vr_rcp_exact(den);
                 const float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
                 p.wx = (b0 * wx0 + b1 * wx1) + b2 * wx2;
                 p.wz = (b0 * wz0 + b1 * wz1) + b2 * wz2;

@@ -49,6 +49,26 @@ __global__ void k_build_quads(const uint8_t* __restrict__ src, int w, int h, uin
                                    | ((uint32_t)src[y1 * w + x0] << 16) | ((uint32_t)src[y1 * w + x1] << 24);
 }
 
+__global__ void k_build_quads_f32(const uint8_t* __restrict__ src, int w, int h, float4* __restrict__ dst)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= w + 2 || iy >= h + 2) return;
+    const int x0 = min(max(ix - 1, 0), w - 1), x1 = min(max(ix, 0), w - 1);
+    const int y0 = min(max(iy - 1, 0), h - 1), y1 = min(max(iy, 0), h - 1);
+    // UNORM8 -> float, correctly rounded, and the differences the bilinear filter forms first
+    const float t00 = (float)src[y0 * w + x0] / 255.0f, t10 = (float)src[y0 * w + x1] / 255.0f;
+    const float t01 = (float)src[y1 * w + x0] / 255.0f, t11 = (float)src[y1 * w + x1] / 255.0f;
+    dst[(size_t)iy * (w + 2) + ix] = make_float4(t00, t10 - t00, t01, t11 - t01);
+}
+
+__global__ void k_decode_rgbf(const uint32_t* __restrict__ src, size_t n, const float* __restrict__ lut, float* __restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t p = src[i];
+        dst[i * 3 + 0] = lut[p & 255u]; dst[i * 3 + 1] = lut[(p >> 8) & 255u]; dst[i * 3 + 2] = lut[(p >> 16) & 255u];
+    }
+}
+
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int tb, DevTex* out, uint8_t** out_mem)
 {
     VR_REQUIRE(host && w > 0 && h > 0 && w <= 16384 && h <= 16384, "bad texture");
@@ -65,7 +85,7 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
     total += sizeof(uint32_t) * kMaxLevels;
     // quad (bilinear footprint) tables for R8 textures
     uint32_t qoff[kMaxLevels] = { 0 };
-    size_t qtable_off = 0, quad_off = 0, quad_dwords = 0;
+    size_t qtable_off = 0, quad_off = 0, quad_dwords = 0, quadf_off = 0;
     if (tb == 1) {
         for (int l = 0; l < levels; l++) {
             int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
@@ -75,7 +95,11 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         qtable_off = total; total += sizeof(uint32_t) * kMaxLevels;
         total = (total + 255) / 256 * 256;
         quad_off = total; total += quad_dwords * sizeof(uint32_t);
+        total = (total + 255) / 256 * 256;
+        quadf_off = total; total += quad_dwords * sizeof(float4);
     }
+    size_t rgbf_off = 0;
+    if (tb == 4) { total = (total + 255) / 256 * 256; rgbf_off = total; total += table_off / 4 * 12; }   // decoded copy of the whole chain
     VR_REQUIRE(total < ((size_t)1 << 31), "texture too large");        // texels are addressed with 32-bit byte offsets
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
@@ -95,14 +119,20 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
                                 (uint32_t*)(mem + off[l]), dw, dh, ctx->d_srgb_lut, ctx->d_srgb_thr);
         sw = dw; sh = dh;
     }
-    out->quad = nullptr; out->qoff = nullptr;
+    out->quad = nullptr; out->qoff = nullptr; out->quadf = nullptr; out->rgbf = nullptr;
+    if (tb == 4) {       // (padding texels between levels are decoded too; nothing reads them)
+        hipLaunchKernelGGL(k_decode_rgbf, dim3(4096), dim3(256), 0, s, (const uint32_t*)mem, table_off / 4, ctx->d_srgb_lut, (float*)(mem + rgbf_off));
+        out->rgbf = (const float*)(mem + rgbf_off);
+    }
     if (tb == 1) {
         VR_TEX_TRY(hipMemcpyAsync(mem + qtable_off, qoff, sizeof(qoff), hipMemcpyHostToDevice, s));
         for (int l = 0; l < levels; l++) {
             int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
             dim3 blk(32, 8), grd((lw + 2 + 31) / 32, (lh + 2 + 7) / 8);
             hipLaunchKernelGGL(k_build_quads, grd, blk, 0, s, mem + off[l], lw, lh, (uint32_t*)(mem + quad_off) + qoff[l]);
+            hipLaunchKernelGGL(k_build_quads_f32, grd, blk, 0, s, mem + off[l], lw, lh, (float4*)(mem + quadf_off) + qoff[l]);
         }
+        out->quadf = (const float4*)(mem + quadf_off);
         out->quad = (const uint32_t*)(mem + quad_off); out->qoff = (const uint32_t*)(mem + qtable_off);
     }
     VR_TEX_TRY(hipGetLastError());
@@ -230,6 +260,37 @@ extern "C" VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, siz
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(din); (void)hipFree(dout);
+    VR_HIP(e);
+    return VR_OK;
+}
+
+// Sweeps every float with an exponent in [-60, 60) (both signs for the reciprocal) and counts the values for which the
+// tile pass's short sequences differ from 1.0f / x and sqrtf(x).  out[0] = reciprocal mismatches, out[1] = square-root
+// mismatches, out[2] = values tested.
+__global__ __launch_bounds__(256) void k_debug_fastmath(unsigned long long* __restrict__ out)
+{
+    const uint32_t lo = (uint32_t)(127 - 60) << 23, hi = (uint32_t)(127 + 60) << 23;
+    unsigned long long bad_r = 0, bad_s = 0, n = 0;
+    for (uint64_t b = (uint64_t)lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; b < hi; b += (uint64_t)gridDim.x * 256) {
+        const float x = __uint_as_float((uint32_t)b);
+        bad_r += __float_as_uint(vr_rcp_exact(x)) != __float_as_uint(1.0f / x);
+        bad_r += __float_as_uint(vr_rcp_exact(-x)) != __float_as_uint(1.0f / -x);
+        bad_s += __float_as_uint(vr_sqrt_exact(x)) != __float_as_uint(sqrtf(x));
+        n++;
+    }
+    atomicAdd(&out[0], bad_r); atomicAdd(&out[1], bad_s); atomicAdd(&out[2], n);
+}
+extern "C" VR_API int vr_debug_fastmath_check(vr_context* ctx, unsigned long long out[3])
+{
+    VR_REQUIRE(ctx && out, "NULL argument");
+    VR_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    VR_HIP(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_debug_fastmath, dim3(8192), dim3(256), 0, ctx->stream, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
     VR_HIP(e);
     return VR_OK;
 }

@@ -468,6 +468,11 @@ class TiledDeferredLightingPass(DeferredLightingPass):
                                                    C.byref(partition) if partition is not None else None),
               "vr_deferred_light_tiled")
 
+    def Status(self):
+        """Waits for the passes queued so far; raises VrError(VR_ERR_OVERFLOW) if a tile kept more than
+        VR_TILE_LIGHT_CAP lights since the last call (the launch itself stays asynchronous)."""
+        check(self.ctx.lib.vr_deferred_tiled_status(self.ctx.handle), "vr_deferred_tiled_status")
+
 
 def synthetic_point_lights(n, world_size, heightmap, max_height=400.0, seed=9001):
     """positions uniform in the world xz-square at terrain height + U(2,30), range U(20,80),
