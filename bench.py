@@ -77,6 +77,49 @@ def cpu_baseline(size, hm, al, params_fn, ambient, cam_fn):
     }
 
 
+def cpu_quadtree_line(args):
+    """BASELINE config 1: source/terrain's quadtree LOD update on a 256^2 heightmap, fixed (reference default) camera,
+    CPU only - the oracle's restatement of QuadTree::Split / NodeSelect / UpdateTransforms / SetHeight timed on this
+    host's cores, single-threaded like the reference's main thread.  No GPU call is made."""
+    import ctypes as C
+    import numpy as np
+    from oracle import pyoracle as po
+    from vrenderer_amd import capi
+    from vrenderer_amd.scene import DEFAULT_EYE, DEFAULT_TARGET, params, scaled_camera
+    po.build()
+    size = 256
+    hm = po.synth_heightmap(size)
+    al = po.synth_albedo(size, hm)
+    p = params(size)
+    eye, tgt = scaled_camera((DEFAULT_EYE, DEFAULT_TARGET), size)
+    reps = max(1, args.steps) * 1000
+    t_build = min(po.lib().orc_time_tree_build(C.byref(p), hm.ctypes.data_as(C.c_void_p), size, size) for _ in range(5))
+    ot = po.OracleTerrain(p, hm, al)
+    views = (capi.View * 1)(po.view_from_camera(eye, tgt, 1920, 1080))
+    sel = C.c_int()
+    po.lib().orc_time_select(ot.handle, views, 1, 400.0, max(1, args.warmup) * 100, C.byref(sel))          # warm-up
+    t_sel = min(po.lib().orc_time_select(ot.handle, views, 1, 400.0, reps, C.byref(sel)) for _ in range(3))
+    t_seth = min(po.lib().orc_time_set_height(ot.handle) for _ in range(5))
+    n_sel = int(sel.value)                      # orc_time_select reports the per-repetition count
+    ot.close()
+    us = t_sel / reps * 1e6
+    print(json.dumps({
+        "metric": "quadtree LOD update (NodeSelect + UpdateTransforms) per frame, CPU", "value": round(us, 4), "unit": "us/frame",
+        "n_gpus": 0, "steps": reps, "warmup": max(1, args.warmup) * 100, "ms_per_step": round(us * 1e-3, 7), "higher_is_better": False,
+        "scaling": "none", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 1: source/terrain quadtree LOD update, 256^2 heightmap (8 LODs, 87,381 nodes), reference "
+                               "default camera scaled to the surface, 1920x1080 view, CPU only; restatement (oracle/vr_oracle.c) of "
+                               "QuadTree.cpp:80-131,164-232 + TerrainPass.cpp:234-256", "heightmap": size,
+                   "selected_nodes": n_sel},
+        "cpu_baseline": {"value": round(us, 4), "unit": "us/frame", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+                         "sample": f"best of 3 x {reps} NodeSelect+UpdateTransforms calls; tree build (Split) best of 5; SetHeight best of 5",
+                         "quadtree_build_s": round(t_build, 5), "set_height_minmax_s": round(t_seth, 5)},
+        "roofline": None,
+        "note": "parity unpinned (no reference fixtures exist); the device counterpart of this work is k_select (~22 us, latency-bound) "
+                "and the mip-style SetHeight reduction",
+    }), flush=True)
+
+
 def ot_num_lods(size):
     return min(11, int(math.log2(size)))
 
@@ -105,10 +148,22 @@ def main():
     ap.add_argument("--exchange", choices=["ldr", "hdr"], default="ldr",
                     help="N>1: what the all-gather carries. ldr (default): each rank tone-maps its tiles (ToneMappingPass, "
                          "histogram all-reduced over the ranks) and RGB8 tiles are gathered, 3 B/px; hdr: RGB16F tiles, 6 B/px")
+    ap.add_argument("--lights", type=int, default=1,
+                    help="BASELINE config 5: N > 1 lights the frame with 1 sun + N-1 point lights (seed 9001, ranges 20-80) through "
+                         "the tiled pass (per-tile LDS light culling) instead of the streaming pass")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="with --emulate-world N: no process group; this one GPU renders and lights rank R's share of the N-way "
+                         "screen-tile split (what one rank of an N-GPU job computes per frame, without the exchange)")
+    ap.add_argument("--emulate-world", type=int, default=None)
+    ap.add_argument("--config", choices=["gpu", "cpu-quadtree"], default="gpu",
+                    help="cpu-quadtree = BASELINE config 1: the reference's CPU-side quadtree work on a 256^2 heightmap, "
+                         "fixed camera, no GPU call at all")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share cuda:0 and the exchange goes through gloo on host copies (RCCL refuses "
                          "two ranks on one device); exercises the N>1 control flow on a one-GPU box, timings are meaningless")
     args = ap.parse_args()
+    if args.config == "cpu-quadtree":
+        return cpu_quadtree_line(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,7 +204,11 @@ def main():
     tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
     rt = vr.RenderTargets(ctx).Init(W, H)
     lights = [vr.reference_sun()]
-    deferred = vr.DeferredLightingPass(ctx)
+    tiled = args.lights > 1
+    if tiled:
+        lights += vr.synthetic_point_lights(args.lights - 1, float(size), hm, 400.0, seed=9001)
+    deferred = vr.TiledDeferredLightingPass(ctx) if tiled else vr.DeferredLightingPass(ctx)
+    light_kernel = "k_deferred_tiled" if tiled else "k_deferred"
     rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
 
     shadow_map = None
@@ -157,6 +216,37 @@ def main():
         shadow_map = vr.CascadedShadowMap(ctx, vr.default_shadow_params(float(size), depth_bias=0.002))
     part = None
     ctx_comm = ctx
+    emu = args.emulate_world is not None
+    if emu:
+        # one rank's share of an N-way split on this one GPU: packed tiles out of the lighting pass, tone-mapped to the
+        # RGB8 tiles the rank would hand to the all-gather (histogram of its own pixels only: no all-reduce here)
+        if use_dist or args.emulate_rank is None or not (0 <= args.emulate_rank < args.emulate_world):
+            raise SystemExit("--emulate-rank R --emulate-world N (0 <= R < N) runs without a process group")
+        part = vr.Partition(args.emulate_rank, args.emulate_world)
+        info = partition_info(W, H, args.emulate_rank, args.emulate_world)
+        rows = (info["packed_bytes"] + vr.VR_OWNER_TILE * 8 - 1) // (vr.VR_OWNER_TILE * 8)
+        emu_hdr = [vr.HdrImage(ctx, vr.VR_OWNER_TILE, rows) for _ in range(2)]
+        hdr = frame = emu_hdr[0]
+        emu_ldr = args.exchange == "ldr"
+        if emu_ldr:
+            # as in the N-rank loop: the tone-map stage of frame i runs on the exchange stream under the rendering of frame i+1
+            import torch
+            torch.cuda.set_device(local_rank)
+            main_stream = torch.cuda.current_stream()
+            ctx.set_stream(main_stream.cuda_stream)
+            comm_stream = torch.cuda.Stream()
+            ctx_comm = vr.Context(local_rank)
+            ctx_comm.set_stream(comm_stream.cuda_stream)
+            tmp = vr.default_tonemap_params()
+            tm = vr.ToneMappingPass(ctx_comm)
+            tm.AdvanceFrame(1.0 / 60.0)
+            ldr_img = vr.LdrImage(ctx_comm, W, H)     # capacity of a whole frame; the packed RGB8 tiles use the front of it
+            emu_render_done = [torch.cuda.Event() for _ in range(2)]
+            emu_tm_done = [torch.cuda.Event() for _ in range(2)]
+        from vrenderer_amd import partition as pt
+        tx_ = pt.owner_grid(W, H)[0]
+        owned_px = sum(min(128, W - (t % tx_) * 128) * min(128, H - (t // tx_) * 128)
+                       for t in pt.owned_tiles(W, H, args.emulate_rank, args.emulate_world))
     if use_dist:
         part = vr.Partition(rank, world)
         info = partition_info(W, H, rank, world)
@@ -209,7 +299,7 @@ def main():
         from vrenderer_amd import partition as pt
         tx_ = pt.owner_grid(W, H)[0]
         owned_px = sum(min(128, W - (t % tx_) * 128) * min(128, H - (t // tx_) * 128) for t in pt.owned_tiles(W, H, rank, world))
-    else:
+    elif not emu:
         hdr = vr.HdrImage(ctx, W, H)
         frame = hdr
         owned_px = W * H
@@ -237,23 +327,41 @@ def main():
         else:
             dist.all_reduce(t_i32)
 
+    def light(v, out_img, p):
+        if tiled:
+            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p)
+        else:
+            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p, shadow_map=shadow_map)
+
     def step(i):
         v, vnext = views[i % 120], views[(i + 1) % 120]
         if shadow_map is not None:                  # every rank renders the whole (small) shadow map
             shadow_map.SetupForPlanarViewStable(lights[0], v)
             shadow_map.RenderTerrain(tp)
         if not use_dist:
-            tp.Render(v, v, rt, rp, None)
+            out_img = emu_hdr[i % 2] if emu else hdr
+            if emu and emu_ldr:
+                main_stream.wait_event(emu_tm_done[i % 2])         # the packed tiles of two frames ago have been consumed
+            tp.Render(v, v, rt, rp, part)
             if not args.no_prepare and shadow_map is None:
-                tp.Prepare(vnext, rt, rp, None)      # frame i+1's geometry is built under frame i's tile pass
-            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr, None, shadow_map=shadow_map)
+                tp.Prepare(vnext, rt, rp, part)      # frame i+1's geometry is built under frame i's tile pass
+            light(v, out_img, part)
+            if emu and emu_ldr:
+                emu_render_done[i % 2].record(main_stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(emu_render_done[i % 2])
+                    tm.ResetHistogram()
+                    tm.AddFrameToHistogram(tmp, out_img, W, H, part)
+                    tm.ComputeExposure(tmp)
+                    tm.Render(tmp, out_img, ldr_img, W, H, part)
+                    emu_tm_done[i % 2].record(comm_stream)
             return
         b = i % nbuf
         main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
         tp.Render(v, v, rt, rp, part)
         if not args.no_prepare and shadow_map is None:
             tp.Prepare(vnext, rt, rp, part)
-        deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_bufs[b], part, shadow_map=shadow_map)
+        light(v, hdr_bufs[b], part)
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
@@ -278,7 +386,9 @@ def main():
             post_done[b].record(post_stream)
 
     def sync():
-        if use_dist:
+        if emu and emu_ldr:
+            torch.cuda.synchronize()
+        elif use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -289,7 +399,7 @@ def main():
         step(i)
     sync()
     ctx.timing_enable(True)          # HIP events around every kernel, on the stream they are launched on
-    side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx)) if c is not ctx]
+    side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx_comm)) if c is not ctx]
     for c in side_ctxs:
         c.timing_enable(True)
     t0 = time.perf_counter()
@@ -303,6 +413,8 @@ def main():
         timings.update(c.timing_collect())
         c.timing_enable(False)
     n_nodes = tp.num_chunks()
+    if tiled:
+        deferred.Status()            # raises if a tile kept more than VR_TILE_LIGHT_CAP lights (the result would be truncated)
 
     verified = None
     if args.verify:
@@ -319,7 +431,7 @@ def main():
         if shadow_map is not None:
             shadow_map.SetupForPlanarViewStable(lights[0], last)
             shadow_map.RenderTerrain(tp)
-        deferred.Render(last, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, ref_img, None, shadow_map=shadow_map)
+        light(last, ref_img, None)
         if use_dist and ldr:
             tm_ref = vr.ToneMappingPass(ctx)
             tm_ref.AdvanceFrame(1.0 / 60.0)
@@ -347,12 +459,18 @@ def main():
 
         # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for wide
         # reads, + WRITE_SIZE; see tools/summarize_pmc.py).  They were taken on the N=1 8K workload.
-        pmc = {}
-        try:
-            if world == 1 and (W, H) == (7680, 4320):
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        except Exception:
-            pmc = {}
+        pmc, sq = {}, {}
+        pmc_file = "profiles/r02_pmc_traffic_lights.json" if tiled else "profiles/r02_pmc_traffic.json"
+        sq_file = "profiles/r02_pmc_sq_lights.json" if tiled else "profiles/r02_pmc_sq.json"
+        if world == 1 and not emu and (W, H) == (7680, 4320):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+            except Exception:
+                pmc = {}
+            try:
+                sq = json.load(open(os.path.join(ROOT, sq_file)))
+            except Exception:
+                sq = {}
 
         def roof(name, bytes_per_px, px):
             if name not in timings:
@@ -362,20 +480,38 @@ def main():
             ach = bytes_per_px * px / avg_s / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"), "avg_us": round(avg_s * 1e6, 2),
-                    "bytes_per_launch": bytes_per_px * px,
+                    "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": (pmc_file + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                                  "not measured in this run)") if name in pmc else None,
+                    "avg_us": round(avg_s * 1e6, 2), "bytes_per_launch": bytes_per_px * px,
                     "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"
                             + ("; a kernel that only moves the same bytes reaches 5.6-5.9 TB/s on this part (profiles/r01_stream_layout_ceiling.txt)"
-                               if name == "k_deferred" else "; the tile pass is instruction-issue bound (exact fp32 filtering without texture units), see DESIGN.md 4")}
+                               if name == "k_deferred" else "; instruction-issue bound, see roofline_valu and DESIGN.md 4")}
 
-        roof_deferred = roof("k_deferred", DEFERRED_BYTES_PER_PX, owned_px)
+        def roof_valu(name):
+            """The bound the tile pass and the tiled lighting pass actually run against: vector-instruction issue.  achieved =
+            wave-instructions per launch (SQ_INSTS_VALU from the committed PMC pass of this command) / the live HIP-event
+            duration; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (MI355X_MICROARCH.md, issue-cost row)."""
+            if name not in timings or name not in sq:
+                return None
+            ms, n = timings[name]
+            avg_s = ms / n * 1e-3
+            ach = sq[name]["SQ_INSTS_VALU"] / avg_s / 1e9
+            peak = 1024 * 2.4 / 4.0
+            return {"kernel": name, "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                    "frac": round(ach / peak, 4), "insts_per_launch": sq[name]["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
+                    "source": sq_file}
+
+        roof_deferred = roof(light_kernel, DEFERRED_BYTES_PER_PX, owned_px)
         roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
         out = {
             "metric": "shaded Gpixels/s at 8K terrain", "value": round(value, 3), "unit": "Gpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
-                                   f"1 directional light; full path select+vertex+setup/bin+tile raster(PS)+deferred"
+                                   + (f"1 sun + {args.lights - 1} point lights (seed 9001, range 20-80) through the tiled pass; " if tiled
+                                      else "1 directional light; ")
+                                   + "full path select+vertex+setup/bin+tile raster(PS)+deferred"
                                    + ("; +terrain shadow pass 2048^2 and PCF shadow term" if args.shadows else "")
                                    + (("+tone map (histogram all-reduce)+all-gather of RGB8 tiles+detile" if ldr else
                                        "+all-gather of RGB16F tiles+detile") if use_dist else ""),
@@ -386,20 +522,29 @@ def main():
             # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
             "roofline": roof_deferred,
             "roofline_gbuffer_fill": roof_raster,
+            "roofline_valu": [r for r in (roof_valu("k_raster"), roof_valu(light_kernel) if tiled else None) if r],
             "dominant_kernel_by_time": dominant,
             "kernels": kern,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
         }
+        if emu:
+            out["emulation"] = {"rank": args.emulate_rank, "world": args.emulate_world, "owned_pixels": owned_px,
+                                "what": "one GPU computes this rank's share of the N-way screen-tile split per frame (geometry replicated, "
+                                        "tile pass + lighting" + (" + tone map to packed RGB8 tiles" if emu_ldr else "") + " of owned tiles); "
+                                        "no exchange. value = frame pixels / this rank's frame period = what N such ranks deliver when the "
+                                        "all-gather is fully hidden; unmeasured on N GPUs",
+                                "rank_frame_us": round(ms_per_step * 1e3, 1)}
         if verified is not None:
             out["frame_verified_against_unsplit"] = verified
-        if world == 1 and not use_dist and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows:
+        if world == 1 and not use_dist and not emu and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows:
             # the north star asks for 4K next to 8K: the same workload at 3840x2160, measured by a child process
             # (same code path, its own context) after this process has gone idle
             try:
                 import subprocess
                 ctx.synchronize()
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--width", "3840", "--height", "2160", "--steps", str(args.steps),
-                                    "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-4k"] + (["--fixed-camera"] if args.fixed_camera else []),
+                                    "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-4k", "--lights", str(args.lights)]
+                                   + (["--fixed-camera"] if args.fixed_camera else []),
                                    capture_output=True, text=True, timeout=300)
                 j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                 out["frames_4k"] = {"resolution": [3840, 2160], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
@@ -407,7 +552,7 @@ def main():
                                     "k_raster_avg_us": j["kernels"]["k_raster"]["avg_us"]}
             except Exception as e:
                 out["frames_4k"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)
                 # the device counterpart of the reference's (disabled) heightmap update, for the same heightmap

@@ -303,6 +303,17 @@ VR_API int  vr_deferred_light_shadowed(vr_context* ctx, const vr_view* view, vr_
                                        vr_image* hdr_out, const vr_partition* part,
                                        const vr_shadow_binding* shadow);
 
+/* LdrColor: SRGBA8_UNORM render target (Renderer.h:81-92), width*height*4 bytes of device memory, or - as a
+ * multi-GPU send buffer - the packed RGB8 tiles of one rank (capacity_bytes >= vr_partition_packed_bytes_ldr).
+ * capacity_bytes 0 = width*height*4.  external != NULL wraps caller-owned device memory of that capacity. */
+typedef struct vr_ldr_image vr_ldr_image;
+VR_API int    vr_ldr_image_create(vr_context* ctx, int32_t width, int32_t height, size_t capacity_bytes, void* external_device_ptr,
+                                  vr_ldr_image** out);
+VR_API void   vr_ldr_image_destroy(vr_ldr_image* im);
+VR_API void*  vr_ldr_image_device_ptr(vr_ldr_image* im);
+VR_API size_t vr_ldr_image_capacity(vr_ldr_image* im);
+VR_API int    vr_ldr_image_download(vr_ldr_image* im, void* host, size_t bytes);   /* synchronous; bytes <= capacity */
+
 /* ---- multi-GPU frame assembly (new) -------------------------------- */
 VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_partition* part,
                                      int32_t* tiles_x, int32_t* tiles_y, int32_t* owned,
@@ -316,6 +327,15 @@ VR_API int    vr_partition_prepare(vr_context* ctx, int32_t width, int32_t heigh
  * rebuilds the row-major RGBA16F frame. */
 VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int32_t world_size,
                               vr_image* frame_out);
+
+/* The exchange itself (vr_frame_allgather).  `nccl_comm` is the caller's ncclComm_t for the ranks of the
+ * split (one process per GPU; rank = vr_partition.rank, nranks = world_size).  ncclAllGather of this rank's packed
+ * tiles (vr_partition_packed_bytes of RGB16F out of vr_deferred_light(part)) into `gathered_device`
+ * (world_size x that), queued on the context's stream, followed by vr_frame_detile into frame_out - every rank ends
+ * with the whole row-major RGBA16F frame.  RCCL is resolved at first use from the copy already in the process (the
+ * one that made the communicator), else from librccl.so; libvrterrain.so itself does not link it. */
+VR_API int    vr_frame_allgather(vr_context* ctx, void* nccl_comm, const void* packed_device, void* gathered_device,
+                                 int32_t world_size, vr_image* frame_out);
 
 /* ---- tone mapping to LdrColor ------------------------------- */
 /* donut::render::ToneMappingPass as used by the reference: created with default CreateParameters
@@ -366,6 +386,14 @@ VR_API size_t vr_partition_packed_bytes_ldr(int32_t width, int32_t height, int32
 /* gathered = world_size consecutive packed RGB8 buffers -> row-major SRGBA8 frame (device pointers) */
 VR_API int  vr_frame_detile_ldr(vr_context* ctx, const void* gathered_device, int32_t world_size,
                                 int32_t width, int32_t height, void* ldr_frame_device);
+
+/* The same exchange for tone-mapped frames (3 B/pixel on the wire): ncclAllGather of the packed RGB8 tiles out of
+ * vr_tonemap_render(part) + vr_frame_detile_ldr; and the tone mapper's one real exchange step, the sum of the 256
+ * histogram bins over the ranks (ncclAllReduce, in place, on the tone mapper's context stream) between
+ * vr_tonemap_add_frame_to_histogram(part) and vr_tonemap_compute_exposure. */
+VR_API int  vr_frame_allgather_ldr(vr_context* ctx, void* nccl_comm, const void* packed_ldr_device, void* gathered_device,
+                                   int32_t world_size, int32_t width, int32_t height, void* ldr_frame_device);
+VR_API int  vr_tonemap_allreduce_histogram(vr_tonemap* tm, void* nccl_comm);
 
 /* ---- synthetic inputs (media/ is absent from the reference checkout;
  * SURVEY §8d): seeded integer-hash fBm heightmap and banded albedo, generated on

@@ -67,9 +67,9 @@ namespace vRenderer
     {
         vr_gbuffer* m_GBuffer = nullptr;
         vr_image* m_Hdr = nullptr;
-        vr_image* m_LdrStorage = nullptr;          // LdrColor SRGBA8: width*height*4 bytes, held in a vr_image used as a raw allocation
+        vr_ldr_image* m_Ldr = nullptr;             // LdrColor SRGBA8 (Renderer.h:81-92)
         int m_Width = 0, m_Height = 0;
-        void Release() { vr_image_destroy(m_LdrStorage); vr_image_destroy(m_Hdr); vr_gbuffer_destroy(m_GBuffer); m_LdrStorage = m_Hdr = nullptr; m_GBuffer = nullptr; }
+        void Release() { vr_ldr_image_destroy(m_Ldr); vr_image_destroy(m_Hdr); vr_gbuffer_destroy(m_GBuffer); m_Ldr = nullptr; m_Hdr = nullptr; m_GBuffer = nullptr; }
     public:
         ~RenderTargets() { Release(); }
         bool Init(Device& device, int width, int height)
@@ -78,16 +78,14 @@ namespace vRenderer
             m_Width = width; m_Height = height;
             return Check(vr_gbuffer_create(device.Get(), width, height, &m_GBuffer), "vr_gbuffer_create")
                 && Check(vr_image_create(device.Get(), width, height, nullptr, &m_Hdr), "vr_image_create")
-                && Check(vr_image_create(device.Get(), (width + 1) / 2, height, nullptr, &m_LdrStorage), "vr_image_create");
+                && Check(vr_ldr_image_create(device.Get(), width, height, 0, nullptr, &m_Ldr), "vr_ldr_image_create");
         }
-        void* LdrColor() const { return vr_image_device_ptr(m_LdrStorage); }                 // Renderer.h:81-92
-        size_t LdrColorBytes() const { return (size_t)m_Width * (size_t)m_Height * 4; }
+        void* LdrColor() const { return vr_ldr_image_device_ptr(m_Ldr); }                    // Renderer.h:81-92
+        size_t LdrColorBytes() const { return vr_ldr_image_capacity(m_Ldr); }
         bool DownloadLdrColor(std::vector<uint8_t>& out) const
         {
-            out.resize((size_t)((m_Width + 1) / 2) * (size_t)m_Height * 8);
-            const bool ok = Check(vr_image_download(m_LdrStorage, out.data(), out.size()), "vr_image_download");
             out.resize(LdrColorBytes());
-            return ok;
+            return Check(vr_ldr_image_download(m_Ldr, out.data(), out.size()), "vr_ldr_image_download");
         }
         [[nodiscard]] bool IsUpdateRequired(int width, int height) const { return width != m_Width || height != m_Height; }
         void Clear() { Check(vr_gbuffer_clear(m_GBuffer), "vr_gbuffer_clear"); }            // Renderer.cpp:382

@@ -162,6 +162,35 @@ def test_cpp_host_example_compiles_links_and_fails_soft_without_gpu(product_lib,
         assert r.returncode == 0 and "no device" in r.stdout and "no HIP device" in r.stderr, r.stdout + r.stderr
 
 
+def _build_allgather_example(tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "frame_allgather_example")
+    lib_dir = os.path.join(ROOT, "vrenderer_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "host", "frame_allgather_example.cpp"), "-o", exe,
+           "-L", lib_dir, "-lvrterrain", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_cpp_allgather_example_compiles_and_fails_soft_without_gpu(product_lib, tmp_path):
+    """The N-rank C++ host (RCCL communicator + vr_frame_allgather_ldr + vr_tonemap_allreduce_histogram) builds against
+    rccl.h and the C ABI; without a device it says so."""
+    import subprocess
+    exe = _build_allgather_example(tmp_path)
+    if _has_gpu(product_lib):
+        pytest.skip("run by the GPU suite")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "no device" in r.stdout, r.stdout + r.stderr
+
+
+def test_library_does_not_link_rccl(product_lib):
+    """RCCL is resolved at first use from the copy in the process (vr_comm.hip): no DT_NEEDED entry for it."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", os.path.join(ROOT, "vrenderer_amd", "lib", "libvrterrain.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in out.lower(), out
+
+
 def test_header_is_valid_c(tmp_path):
     import subprocess
     src = tmp_path / "c_check.c"

@@ -389,6 +389,103 @@ def test_tiled_deferred_1024_lights_matches_oracle(scene256, oracle, gpu_ctx):
         o.close()
 
 
+def _gpu_gbuffer_as_oracle_input(oracle, gpu_ctx, tp, v, w, h):
+    """Terrain G-buffer rendered by the HIP path (bit-exact vs the oracle elsewhere) in the oracle's host layout."""
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    tp.Render(v, v, rt, vr.default_render_params(400.0))
+    gb = oracle.GBufferHost(w, h)
+    for name, dst in (("depth", gb.depth), ("diffuse", gb.diffuse), ("specular", gb.specular), ("normals", gb.normals),
+                      ("emissive", gb.emissive)):
+        dst[...] = rt.download(name).reshape(dst.shape)
+    return rt, gb
+
+
+def test_tiled_deferred_config5_at_scale(scene2048, oracle, gpu_ctx):
+    """BASELINE config 5 at its own scale: the 2048^2 scene, 1 sun + 1023 point lights of the seed-9001 set with their
+    authored ranges (20-80 units), 960x540, flythrough frames.  The tiled pass (per-tile culled lists) must equal the
+    oracle's all-lights loop within the stated per-channel RMS <= 1e-4; its packed (partitioned) output must be
+    the same pixels."""
+    from vrenderer_amd.scene import flythrough_camera
+    from vrenderer_amd.passes import frame_detile, partition_info
+    w, h = 960, 540
+    lights = [vr.reference_sun()] + vr.synthetic_point_lights(1023, 2048.0, scene2048["h"], 400.0, seed=9001)
+    tiled = vr.TiledDeferredLightingPass(gpu_ctx)
+    for frame in (30, 75):
+        v = vr.make_view(*flythrough_camera(frame), w, h)
+        rt, gb = _gpu_gbuffer_as_oracle_input(oracle, gpu_ctx, scene2048["tp"], v, w, h)
+        ref32 = oracle.deferred(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+        sun_only = oracle.deferred(v, gb, lights[:1], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+        touched = np.abs(ref32 - sun_only)[..., :3].max(axis=2) > 1e-4
+        assert touched.mean() > 0.1, "the point lights must reach a good part of the frame for the test to mean anything"
+        hdr = vr.HdrImage(gpu_ctx, w, h)
+        tiled.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+        tiled.Status()                                   # no tile keeps more than VR_TILE_LIGHT_CAP lights in this scene
+        got = oracle.half_to_float(hdr.download()).astype(np.float64)
+        # HdrColor is RGBA16F in the reference too: the stated tolerance is on that output (the format's own rounding
+        # of this frame, oracle half vs oracle float, is already 1.3e-4 RMS)
+        ref16 = oracle.half_to_float(oracle.deferred(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM)).astype(np.float64)
+        for c in range(3):
+            rms = float(np.sqrt(np.mean((got[..., c] - ref16[..., c]) ** 2)))
+            assert rms <= 1e-4, (frame, c, rms)
+        # and everywhere at the rounding level of the RGBA16F output (half: 11 significant bits)
+        assert np.all(np.abs(got[..., :3] - ref32[..., :3]) <= 2.0 ** -10 * np.abs(ref32[..., :3]) + 1e-6)
+        assert 0.3 < float(ref32[..., :3].max()) < 2.0, "the light set is meant to keep the frame in a sane HDR range"
+        if frame == 30:
+            world = 3
+            info = partition_info(w, h, 0, world)
+            gathered = np.zeros(world * info["packed_bytes"] // 2, np.uint16)
+            full = hdr.download()
+            for r in range(world):
+                packed = vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+                tiled.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, packed, vr.Partition(r, world))
+                gathered[r * info["packed_bytes"] // 2:(r + 1) * info["packed_bytes"] // 2] = packed.download(info["packed_bytes"])
+                packed.close()
+            big = vr.HdrImage(gpu_ctx, 128, world * info["max_owned"] * 128)
+            big.upload(gathered)
+            out = vr.HdrImage(gpu_ctx, w, h)
+            frame_detile(gpu_ctx, big.device_ptr, world, out)
+            assert np.array_equal(out.download(), full)
+            big.close(); out.close()
+        hdr.close(); rt.close()
+
+
+def test_tiled_deferred_reports_tile_overflow(scene256, oracle, gpu_ctx):
+    """More than VR_TILE_LIGHT_CAP lights over one 32x32 tile: the excess is dropped in light order and
+    vr_deferred_tiled_status returns VR_ERR_OVERFLOW once (the flag is cleared); a normal list reports VR_OK again."""
+    w, h = 256, 144
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v = vr.make_view(eye, tgt, w, h)
+    rt, gb = _gpu_gbuffer_as_oracle_input(oracle, gpu_ctx, scene256["tp"], v, w, h)
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    tiled = vr.TiledDeferredLightingPass(gpu_ctx)
+    stacked = [vr.point_light((0.0, 60.0, 0.0), 1.0, 500.0, (1.0, 1.0, 1.0)) for _ in range(1100)]     # every tile sees all of them
+    tiled.Render(v, rt, stacked, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    with pytest.raises(vr.VrError) as e:
+        tiled.Status()
+    assert e.value.code == vr.capi.VR_ERR_OVERFLOW
+    # what was kept is exactly the first VR_TILE_LIGHT_CAP lights of the list
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    ref = oracle.deferred(v, gb, stacked[:1024], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+    scale = max(1.0, float(ref[..., :3].max()))
+    assert np.sqrt(np.mean(((got[..., :3] - ref[..., :3]) / scale) ** 2)) <= 1e-3     # 1024 terms of half-rounded light
+    tiled.Status()                                       # cleared by the failing call
+    tiled.Render(v, rt, stacked[:1000], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    tiled.Status()
+    hdr.close(); rt.close()
+
+
+def test_cpp_allgather_example_through_rccl(product_lib, tmp_path):
+    """SURVEY 8b's vr_frame_allgather through the C ABI with a real RCCL communicator (one rank per visible device;
+    world size 1 on a one-GPU box): histogram all-reduce, all-gather of RGB8 tiles, de-tile; the assembled frame equals
+    the unsplit one byte for byte."""
+    import subprocess
+    from tests.test_abi_cpu import _build_allgather_example
+    exe = _build_allgather_example(tmp_path)
+    r = subprocess.run([exe, "--require-gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "differing bytes=0" in r.stdout, r.stdout
+
+
 def test_cpp_host_example(product_lib, tmp_path):
     """The C++ caller of tests/host/frame_example.cpp renders and lights a frame through the C ABI."""
     import subprocess

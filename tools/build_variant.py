@@ -17,5 +17,5 @@ for src in B.SOURCES:
     glob = [f for f in extra if "=" not in f or not f.split("=", 1)[0].endswith(".hip")]
     subprocess.run([B._hipcc(), *B.FLAGS, *glob, *per_file, "-c", os.path.join(B.CSRC, src), "-o", o], check=True)
     objs.append(o)
-subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libvrterrain.so"), *objs], check=True)
+subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libvrterrain.so"), *objs, "-ldl"], check=True)
 print(os.path.join(out, "libvrterrain.so"))

@@ -13,7 +13,7 @@ CSRC = os.path.join(_DIR, "csrc")
 LIB_DIR = os.path.join(_DIR, "lib")
 OBJ_DIR = os.path.join(_DIR, "build")
 LIB = os.path.join(LIB_DIR, "libvrterrain.so")
-SOURCES = ["vr_host.hip", "vr_tex.hip", "vr_select.hip", "vr_raster.hip", "vr_deferred.hip", "vr_tonemap.hip"]
+SOURCES = ["vr_host.hip", "vr_tex.hip", "vr_select.hip", "vr_raster.hip", "vr_deferred.hip", "vr_tonemap.hip", "vr_comm.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

@@ -26,6 +26,7 @@ struct DeferredArgs {
     int num_lights;
     float amb_top[3], amb_bot[3];
     int tiles_x;           // owner tiles per row (packed mode)
+    int exact_pos;         // the light list has positional lights: reconstruct the world position in the checker's arithmetic
     DevLight lights[kMaxLights];
 };
 
@@ -66,12 +67,27 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
     const float rough = vr_max((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
     s.E[0] = vr_half_to_float(e01 & 0xffffu); s.E[1] = vr_half_to_float(e01 >> 16); s.E[2] = vr_half_to_float(e23 & 0xffffu);
     // ReconstructWorldPosition: window -> clip -> world
-    const float cx = ((float)px + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+    float cx, cy;
+    {
+#pragma clang fp contract(off)
+        cx = ((float)px + 0.5f) * a.sx + -1.0f; cy = ((float)py + 0.5f) * a.sy + 1.0f;
+    }
     float wp4[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
     const float rw = fast_rcp(wp4[3]);
     s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
+    if (a.exact_pos) {
+        // Far from the camera clip -> world is ill-conditioned (w = depth * c2w[11] + c2w[15] cancels to a few significant
+        // bits: at depth 0.9999 one rounding moves the point by a world unit).  A directional light does not care, a
+        // point light's distance and direction do, so with positional lights in the list the position is evaluated in the
+        // checker's exact order - no contraction, IEEE divisions (wave-uniform branch; the sun-only pass is unchanged).
+#pragma clang fp contract(off)
+        float e4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
+        s.wp[0] = e4[0] / e4[3]; s.wp[1] = e4[1] / e4[3]; s.wp[2] = e4[2] / e4[3];
+    }
     const float d[3] = { s.wp[0] - a.cam[0], s.wp[1] - a.cam[1], s.wp[2] - a.cam[2] };
     const float dl = fast_rsq(dot3c(d[0], d[1], d[2], d[0], d[1], d[2]));
     s.vi[0] = d[0] * dl; s.vi[1] = d[1] * dl; s.vi[2] = d[2] * dl;      // viewIncident; V = -vi
@@ -402,6 +418,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
     for (int i = 0; i < num_lights; i++) {
         int rc = fill_light(lights[i], a.lights[i], true); if (rc) return rc;
         extra = extra || a.lights[i].type == VR_LIGHT_SPOT || a.lights[i].radius > 0.0f;
+        if (a.lights[i].type != VR_LIGHT_DIRECTIONAL) a.exact_pos = 1;
     }
     const size_t npx = (size_t)gb->w * gb->h;
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
@@ -643,6 +660,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     for (int i = 0; i < 16; i++) a.c2w[i] = view->clip_to_world[i];
     for (int i = 0; i < 3; i++) { a.cam[i] = view->camera_pos[i]; a.amb_top[i] = amb_top[i]; a.amb_bot[i] = amb_bottom[i]; }
     a.w = gb->w; a.h = gb->h; a.sx = 2.0f / (float)gb->w; a.sy = -2.0f / (float)gb->h; a.num_lights = 0;
+    for (int i = 0; i < num_lights; i++) if (ctx->h_lights[i].type != VR_LIGHT_DIRECTIONAL) a.exact_pos = 1;
     const bool packed = part != nullptr;
     VR_REQUIRE(gb->w % 4 == 0, "the tiled pass needs a frame width that is a multiple of 4");
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);

@@ -32,6 +32,7 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
     VR_REQUIRE(device >= 0 && device < n, "device ordinal out of range");
     VR_HIP(hipSetDevice(device));
     vr_context* c = new vr_context();
+    struct Guard { vr_context*& c; ~Guard() { if (c) vr_context_destroy(c); } } guard{ c };   // frees what exists on an early return
     c->device = device;
     c->stream = nullptr;   // default stream until vr_context_set_stream
     for (int i = 0; i < 256; i++) c->h_srgb_lut[i] = (float)srgb_eotf((double)i / 255.0);
@@ -56,7 +57,6 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
             for (int k = 255; k > 0; k--) if (xt >= c->h_srgb_thr[k]) { hi_code = k; break; }
             if (b < kEncTabSize - 1 && hi_code - lo > 1) {
                 vr_set_error("sRGB encode table: bucket %d spans more than one threshold", b);
-                (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); delete c;
                 return VR_ERR_INVALID_ARGUMENT;
             }
         }
@@ -65,6 +65,7 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
         VR_HIP(hipMemcpy(c->d_enc_tab, tab, kEncTabSize, hipMemcpyHostToDevice));
     }
     *out = c;
+    c = nullptr;                 // released to the caller: the guard lets go
     return VR_OK;
 }
 
@@ -353,8 +354,10 @@ extern "C" VR_API int vr_gbuffer_create(vr_context* ctx, int32_t w, int32_t h, v
     if (e != hipSuccess) { delete g; vr_set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); return VR_ERR_OUT_OF_MEMORY; }
     g->depth = (float*)(base + o_depth); g->diffuse = (uint32_t*)(base + o_diff); g->specular = (uint32_t*)(base + o_spec);
     g->normals = (uint2*)(base + o_nrm); g->emissive = (uint2*)(base + o_emi);
+    const int rc = vr_gbuffer_clear(g);
+    if (rc != VR_OK) { (void)hipFree(base); delete g; return rc; }      // the caller owns the object only on success
     *out = g;
-    return vr_gbuffer_clear(g);
+    return VR_OK;
 }
 
 extern "C" VR_API void vr_gbuffer_destroy(vr_gbuffer* g)
@@ -491,6 +494,41 @@ extern "C" VR_API int vr_image_upload(vr_image* im, const void* host, size_t byt
     return VR_OK;
 }
 
+// ---- LDR image (LdrColor, Renderer.h:81-92) ------------------------------------------------
+extern "C" VR_API int vr_ldr_image_create(vr_context* ctx, int32_t w, int32_t h, size_t capacity_bytes, void* external, vr_ldr_image** out)
+{
+    VR_REQUIRE(ctx && out, "NULL argument");
+    VR_REQUIRE(w > 0 && h > 0, "bad image size");
+    VR_HIP(hipSetDevice(ctx->device));
+    const size_t cap = capacity_bytes ? capacity_bytes : (size_t)w * h * 4;
+    void* data = external;
+    if (!external) {
+        hipError_t e = hipMalloc(&data, cap);
+        if (e != hipSuccess) { vr_set_error("hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return VR_ERR_OUT_OF_MEMORY; }
+    }
+    vr_ldr_image* im = new vr_ldr_image();
+    im->ctx = ctx; im->w = w; im->h = h; im->data = data; im->owned = external == nullptr; im->capacity_bytes = cap;
+    *out = im;
+    return VR_OK;
+}
+extern "C" VR_API void vr_ldr_image_destroy(vr_ldr_image* im)
+{
+    if (!im) return;
+    if (im->owned) { (void)hipSetDevice(im->ctx->device); (void)hipFree(im->data); }
+    delete im;
+}
+extern "C" VR_API void* vr_ldr_image_device_ptr(vr_ldr_image* im) { return im ? im->data : nullptr; }
+extern "C" VR_API size_t vr_ldr_image_capacity(vr_ldr_image* im) { return im ? im->capacity_bytes : 0; }
+extern "C" VR_API int vr_ldr_image_download(vr_ldr_image* im, void* host, size_t bytes)
+{
+    VR_REQUIRE(im && host, "NULL argument");
+    VR_REQUIRE(bytes <= im->capacity_bytes, "byte count exceeds the image");
+    VR_HIP(hipSetDevice(im->ctx->device));
+    VR_HIP(hipMemcpyAsync(host, im->data, bytes, hipMemcpyDeviceToHost, im->ctx->stream));
+    VR_HIP(hipStreamSynchronize(im->ctx->stream));
+    return VR_OK;
+}
+
 // ---- screen-tile partition ----------------------------------------------
 static void owner_grid(int w, int h, int* tx, int* ty)
 {
@@ -553,7 +591,7 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
     for (int r = 0; r < world; r++) { int c = count_owned(tx, ty, r, world); if (c > max_owned) max_owned = c; }
     std::vector<int32_t> owned, slot((size_t)tx * ty), raster;
     std::vector<int> next(world, 0);
-    const int rtile = 1 << vr_raster_tile_shift(w, h);
+    const int rtile = 1 << vr_raster_tile_shift(w, h, world);
     const int rtx = (w + rtile - 1) / rtile, rty = (h + rtile - 1) / rtile;
     const int sub = VR_OWNER_TILE / rtile;
     for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++) {

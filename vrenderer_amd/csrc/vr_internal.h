@@ -31,9 +31,13 @@ constexpr int kTrisPerInst = kGrid * kGrid * 2; // 2048
 constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of large frames; also the upper bound of either size
 // Tile edge of the raster / bin grid for a w x h target: 64, or 32 when 64-pixel tiles would leave the chip's
 // 1024 workgroup slots short of work (measured: 1080p tile pass 140 -> 92 us, 4K 219 -> 208, 8K 568 -> 644).
-inline int vr_raster_tile_shift(int w, int h)
+// A rank of an N-way split rasterises 1/N of the tiles, scattered over a frame whose triangles stay large: 32-pixel
+// tiles pay there only once the share drops below ~1.5 launch waves (measured at 8K on one GPU: N=2 274 vs 391 us,
+// N=4 153 vs 192 us with 64- vs 32-pixel tiles, N=8 107 vs 83 us).
+inline int vr_raster_tile_shift(int w, int h, int world = 1)
 {
     const long tiles64 = (long)((w + 63) / 64) * (long)((h + 63) / 64);
+    if (world > 1) return tiles64 / world < 1536 ? 5 : 6;
     return tiles64 < 4096 ? 5 : 6;
 }
 constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
@@ -154,11 +158,20 @@ struct vr_image {
     size_t capacity_bytes;
 };
 
+struct vr_ldr_image {
+    vr_context* ctx;
+    int w, h;
+    void* data;
+    bool owned;
+    size_t capacity_bytes;
+};
+
 // Everything one frame's geometry stages produce and its tile pass consumes.  Two sets alternate so
 // that the geometry of frame N+1 can be built while the tile pass of frame N still reads its own.
 struct GeoSet {
     uint32_t* d_node_ids = nullptr;      // select outputs
     vr_instance* d_instances = nullptr;
+    uint32_t* d_sel_scratch = nullptr;   // k_select's two frontiers + selected list
     uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled
@@ -204,6 +217,8 @@ struct vr_terrain {
     bool main_dep_pending = false, raster_begin_recorded = false;
 };
 
+struct vr_tonemap;
+vr_context* vr_tonemap_context(vr_tonemap* tm);
 // ---- cross-TU entry points ----------------------------------------------------------
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
                           DevTex* out, uint8_t** out_mem);

@@ -525,10 +525,12 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict
         order[atomicAdd(&start[cnt ? __clz((int)cnt) : 32], 1u)] = tile;
     }
     __syncthreads();                                      // every count has been read; they are consumed (zeroed) below
-    const int per = (n_tiles + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, n_tiles);
+    // A rank's bins are the candidates' only (k_setup / k_fill count owned tiles alone): scan that list, not the frame.
+    const int n_scan = cand ? n_cand : n_tiles;
+    const int per = (n_scan + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, n_scan);
     uint32_t s = 0;
-    for (int i = b; i < e; i++) s += tile_count[i];
+    for (int i = b; i < e; i++) s += tile_count[cand ? cand[i] : i];
     partial[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -540,7 +542,10 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict
     uint32_t run = partial[tid] - s;
     // the counts are consumed here: zero them for the next frame (saves a memset per frame); the
     // rasteriser gets a bin's length from cursor - offset once k_fill has run
-    for (int i = b; i < e; i++) { tile_offset[i] = run; tile_cursor[i] = run; run += tile_count[i]; tile_count[i] = 0u; }
+    for (int i = b; i < e; i++) {
+        const int t = cand ? cand[i] : i;
+        tile_offset[t] = run; tile_cursor[t] = run; run += tile_count[t]; tile_count[t] = 0u;
+    }
     if (tid == 1023) {
         counters[C_BINTOTAL] = partial[1023];
         if (partial[1023] > capacity) atomicOr(&counters[C_FLAGS], 2u);
@@ -1225,7 +1230,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     if (a.vy0 < 0) a.vy0 = 0;
     if (a.vx1 > w - 1) a.vx1 = w - 1;
     if (a.vy1 > h - 1) a.vy1 = h - 1;
-    a.tile_shift = vr_raster_tile_shift(w, h);
+    a.tile_shift = vr_raster_tile_shift(w, h, world);
     { const int rt = 1 << a.tile_shift; a.rtx = (w + rt - 1) / rt; a.rty = (h + rt - 1) / rt; }
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared; a.wireframe = rp->wireframe ? 1 : 0;

@@ -23,6 +23,8 @@ struct vr_tonemap {
     float* d_exposure;       // [0] adapted luminance
 };
 
+vr_context* vr_tonemap_context(vr_tonemap* tm) { return tm->ctx; }
+
 struct TmArgs {
     int w, h, tiles_x;
     float scale, bias;                       // log-luminance -> [0, 1]

@@ -204,34 +204,32 @@ class HdrImage:
 
 
 class LdrImage:
-    """LdrColor, SRGBA8_UNORM (Renderer.h:81-92): width*height*4 bytes of device memory (held in a vr_image
-    that is only used as a raw allocation), or packed RGB8 tiles when used as a multi-GPU send buffer."""
+    """LdrColor, SRGBA8_UNORM (Renderer.h:81-92): a vr_ldr_image of width*height*4 bytes of device memory, or the
+    packed RGB8 tiles of one rank when used as a multi-GPU send buffer (capacity_bytes)."""
 
     def __init__(self, ctx, width, height, external_ptr=None, capacity_bytes=None):
         self.ctx, self.width, self.height = ctx, width, height
         self.capacity = capacity_bytes if capacity_bytes is not None else width * height * 4
-        self._img = None
-        if external_ptr:
-            self._ptr = external_ptr
-        else:
-            rows = (self.capacity + 8 * 1024 - 1) // (8 * 1024)
-            self._img = HdrImage(ctx, 1024, max(1, rows))
-            self._ptr = self._img.device_ptr
+        self.owned = not external_ptr
+        h = C.c_void_p()
+        check(ctx.lib.vr_ldr_image_create(ctx.handle, width, height, self.capacity, C.c_void_p(external_ptr or 0), C.byref(h)),
+              "vr_ldr_image_create")
+        self.handle = h
 
     @property
     def device_ptr(self):
-        return self._ptr
+        return self.ctx.lib.vr_ldr_image_device_ptr(self.handle)
 
     def download(self, nbytes=None):
-        assert self._img is not None, "download is only available for library-owned LDR images"
         n = nbytes if nbytes is not None else self.width * self.height * 4
-        raw = self._img.download(nbytes=(n + 1) // 2 * 2).view(np.uint8)[:n]
+        raw = np.empty(n, np.uint8)
+        check(self.ctx.lib.vr_ldr_image_download(self.handle, _vp(raw), n), "vr_ldr_image_download")
         return raw.reshape(self.height, self.width, 4) if nbytes is None else raw
 
     def close(self):
-        if self._img is not None:
-            self._img.close()
-            self._img = None
+        if self.handle:
+            self.ctx.lib.vr_ldr_image_destroy(self.handle)
+            self.handle = None
 
 
 def default_tonemap_params(**kw):
@@ -474,9 +472,11 @@ class TiledDeferredLightingPass(DeferredLightingPass):
         check(self.ctx.lib.vr_deferred_tiled_status(self.ctx.handle), "vr_deferred_tiled_status")
 
 
-def synthetic_point_lights(n, world_size, heightmap, max_height=400.0, seed=9001):
+def synthetic_point_lights(n, world_size, heightmap, max_height=400.0, seed=9001, intensity=50.0):
     """positions uniform in the world xz-square at terrain height + U(2,30), range U(20,80),
-    colour uniform; numpy PCG64 with a fixed seed."""
+    colour uniform; numpy PCG64 with a fixed seed.  The survey leaves the intensity open: 50 keeps the lit terrain
+    of the 2048 world within [0, 1] (peak ~0.9 with all 1023 lights), the range the 1e-4 RMS tolerance is meant for -
+    at 400 the frame peaks near 8, where one half-precision ulp of the RGBA16F output is already 4e-3."""
     rng = np.random.default_rng(seed)
     size = heightmap.shape[0]
     xz = rng.uniform(-0.5 * world_size, 0.5 * world_size, (n, 2))
@@ -485,7 +485,7 @@ def synthetic_point_lights(n, world_size, heightmap, max_height=400.0, seed=9001
     y = heightmap[tz, tx].astype(np.float64) / 255.0 * max_height + rng.uniform(2.0, 30.0, n)
     rad = rng.uniform(20.0, 80.0, n)
     col = rng.uniform(0.0, 1.0, (n, 3))
-    return [point_light((xz[i, 0], y[i], xz[i, 1]), 400.0, rad[i], col[i]) for i in range(n)]
+    return [point_light((xz[i, 0], y[i], xz[i, 1]), intensity, rad[i], col[i]) for i in range(n)]
 
 
 def synth_heightmap(ctx, size, seed=1337):
