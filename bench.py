@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--exchange", choices=["ldr", "hdr"], default="ldr",
                     help="N>1: what the all-gather carries. ldr (default): each rank tone-maps its tiles (ToneMappingPass, "
                          "histogram all-reduced over the ranks) and RGB8 tiles are gathered, 3 B/px; hdr: RGB16F tiles, 6 B/px")
+    ap.add_argument("--no-dispatch-events", action="store_true",
+                    help="explicit hipEventRecord packets around the tile pass instead of the dispatch-stamped events (A/B of the launch gap)")
     ap.add_argument("--lights", type=int, default=1,
                     help="BASELINE config 5: N > 1 lights the frame with 1 sun + N-1 point lights (seed 9001, ranges 20-80) through "
                          "the tiled pass (per-tile LDS light culling) instead of the streaming pass")
@@ -199,6 +201,8 @@ def main():
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    if args.no_dispatch_events:
+        ctx.set_dispatch_events(False)
     hm = vr.synth_heightmap(ctx, size, 1337)
     al = vr.synth_albedo(ctx, size, hm, 4242)
     tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)

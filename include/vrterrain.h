@@ -148,7 +148,10 @@ VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submi
  * stages (select, vertex, setup, bins) on a second stream, so that they overlap whatever the caller
  * queued on the context's stream after the previous vr_terrain_render (typically vr_deferred_light
  * of the previous frame); the tile pass stays on the context's stream.  0 = everything on one stream. */
-enum { VR_OPT_ASYNC_GEOMETRY = 1 };
+/* VR_OPT_DISPATCH_EVENTS (default 1): the two big kernels of a frame (tile pass, lighting pass) are launched with
+ * hipExtLaunchKernelGGL, whose start/stop events are stamped by the dispatch itself, and the stop events double as the
+ * cross-stream dependencies - no event-record packets sit between the two kernels.  0 = explicit hipEventRecord. */
+enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2 };
 VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);

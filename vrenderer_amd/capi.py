@@ -23,6 +23,7 @@ VR_LIGHT_POINT = 3
 VR_K_COUNT = 16
 VR_TONEMAP_BINS = 256
 VR_OPT_ASYNC_GEOMETRY = 1
+VR_OPT_DISPATCH_EVENTS = 2
 
 
 class TerrainParams(C.Structure):

@@ -81,6 +81,7 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
     }
     timing_reset(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -94,8 +95,9 @@ extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
 extern "C" VR_API int vr_context_set_option(vr_context* c, int option, int value)
 {
     VR_REQUIRE(c != nullptr, "ctx is NULL");
-    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY, "unknown option");
-    c->async_geometry = value != 0;
+    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS, "unknown option");
+    if (option == VR_OPT_ASYNC_GEOMETRY) c->async_geometry = value != 0;
+    else { VR_HIP(hipStreamSynchronize(c->stream)); c->dispatch_events = value != 0; c->last_stop = nullptr; }
     return VR_OK;
 }
 
@@ -116,26 +118,49 @@ static hipEvent_t take_event(vr_context* c)
 }
 VrKernelScope::VrKernelScope(vr_context* ctx, int id) : VrKernelScope(ctx, id, ctx->stream) {}
 VrKernelScope::VrKernelScope(vr_context* ctx, int id, hipStream_t stream) : VrKernelScope(ctx, id, stream, false) {}
+static hipEvent_t ring_event(vr_context* c)
+{
+    constexpr size_t kRing = 64;          // far more than the launches a later wait can still refer to
+    if (c->ev_ring.size() < kRing) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_ring.push_back(e);
+        return e;
+    }
+    hipEvent_t e = c->ev_ring[c->ev_ring_pos];
+    c->ev_ring_pos = (c->ev_ring_pos + 1) % kRing;
+    return e;
+}
 VrKernelScope::VrKernelScope(vr_context* ctx, int id_, hipStream_t stream, bool attach_) : c(ctx), st(stream), attach(attach_), id(id_)
 {
-    if (!c->timing) return;
-    e0 = take_event(c); e1 = take_event(c);
-    if (!e0 || !e1) {
-        if (e0) c->ev_pool.push_back(e0);
-        if (e1) c->ev_pool.push_back(e1);
-        e0 = e1 = nullptr; return;
+    if (c->timing) {
+        e0 = take_event(c); e1 = take_event(c);
+        if (!e0 || !e1) {
+            if (e0) c->ev_pool.push_back(e0);
+            if (e1) c->ev_pool.push_back(e1);
+            e0 = e1 = nullptr; return;
+        }
+        pooled = true;
+        if (!attach) { (void)hipEventRecord(e0, st); commit(); }
+    } else if (attach && c->dispatch_events) {
+        e0 = ring_event(c); e1 = ring_event(c);
+        if (!e0 || !e1) e0 = e1 = nullptr;
     }
-    if (!attach) { (void)hipEventRecord(e0, st); commit(); }
 }
 void VrKernelScope::commit()
 {
-    if (committed || !e0 || !e1) return;
+    if (committed || !pooled || !e0 || !e1) return;
     c->ev_begin.push_back(e0); c->ev_end.push_back(e1); c->ev_id.push_back(id);
     committed = true;
 }
+void VrKernelScope::launched()
+{
+    commit();
+    if (st == c->stream) c->last_stop = e1;
+}
 VrKernelScope::~VrKernelScope()
 {
-    if (!e0 || !e1) return;
+    if (!e0 || !e1 || !pooled) return;
     if (!attach) (void)hipEventRecord(e1, st);
     else if (!committed) { c->ev_pool.push_back(e0); c->ev_pool.push_back(e1); }
 }

@@ -115,6 +115,13 @@ struct vr_context {
     // shadow map's and the main view's geometry every frame)
     std::vector<PartTables*> part_tables;
     bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
+    // VR_OPT_DISPATCH_EVENTS: the tile pass and the lighting pass are launched with hipExtLaunchKernelGGL, whose start/stop
+    // events are stamped by the dispatch itself; the stop events double as the cross-stream dependencies (tile pass done ->
+    // its geometry set is free; lighting pass done -> the next frame's geometry may start), so no event-record packets
+    // sit between the two big kernels of a frame.  Outside timing runs the events come from this ring.
+    bool dispatch_events = true;
+    std::vector<hipEvent_t> ev_ring; size_t ev_ring_pos = 0;
+    hipEvent_t last_stop = nullptr;     // stop event of the most recent dispatch-stamped launch on `stream`
     // light list of vr_deferred_light_tiled
     DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights;
     uint32_t* d_flags = nullptr;
@@ -128,6 +135,7 @@ struct vr_context {
 // Records a begin/end event pair around one kernel launch when timing is enabled.
 struct VrKernelScope {
     vr_context* c; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr; bool attach = false; int id = 0; bool committed = false;
+    bool pooled = false;            // the pair came from the timing pool (else from the context's ring: dependencies only)
     VrKernelScope(vr_context* ctx, int id);                       // on the context's stream
     VrKernelScope(vr_context* ctx, int id, hipStream_t stream);   // on another stream of the same device
     // attach = true: the events are not recorded as separate stream operations; the launch passes them to
@@ -137,11 +145,12 @@ struct VrKernelScope {
     // the pair enters the context's list only once something will stamp it (attach = true: after the launch was issued;
     // a scope that returns early without launching hands its events back instead of leaving a never-recorded pair)
     void commit();
+    void launched();                // the dispatch that stamps the pair has been issued
     ~VrKernelScope();
 };
 // launch under a scope created with attach = true
 #define VR_LAUNCH_TIMED(scope, kernel, grid, block, stream, ...) do { \
-        if ((scope).e0 && (scope).e1) { hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (scope).e0, (scope).e1, 0, __VA_ARGS__); (scope).commit(); } \
+        if ((scope).e0 && (scope).e1) { hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (scope).e0, (scope).e1, 0, __VA_ARGS__); (scope).launched(); } \
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__); } while (0)
 
 struct vr_gbuffer {
@@ -186,6 +195,7 @@ struct GeoSet {
     uint32_t* d_bin_entries = nullptr;
     int scratch_tiles = 0;
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
+    hipEvent_t raster_done = nullptr;    // what the geometry stream waits on before reusing this set: ev_raster_done, or the tile pass's own stop event
     bool raster_recorded = false, have_selection = false;
     // vr_terrain_prepare: geometry already built for exactly these inputs
     bool prepared = false;
@@ -215,6 +225,7 @@ struct vr_terrain {
     hipStream_t geo_stream = nullptr;
     hipEvent_t ev_main_dep = nullptr, ev_raster_begin = nullptr;   // ev_raster_begin: the context's stream reached the last tile pass
     bool main_dep_pending = false, raster_begin_recorded = false;
+    hipEvent_t start_hint = nullptr;        // vr_terrain_prepare starts its geometry behind this: ev_raster_begin, or the previous lighting pass's stop event
 };
 
 struct vr_tonemap;

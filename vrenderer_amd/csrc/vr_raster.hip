@@ -1253,7 +1253,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
         t->main_dep_pending = true;
     }
     // after the tile pass that last read this set, and after anything the context's stream did to the terrain
-    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.ev_raster_done, 0));
+    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.raster_done, 0));
     if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); t->main_dep_pending = false; }
     int rc;
     if (selection_from == nullptr) {                                   // TerrainPass.cpp:173-190
@@ -1330,7 +1330,7 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     // device, and without this the geometry would become runnable one pass earlier and share the device
     // with the previous frame's lighting pass (bandwidth-bound) instead of with a tile pass (which leaves
     // half of every CU's wave slots free).
-    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_raster_begin, 0));
+    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, t->start_hint, 0));
     if ((rc = launch_geometry(t, g, nullptr, view, rp, a, pt))) return rc;
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
     return VR_OK;
@@ -1365,8 +1365,11 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
     const int grid = pt ? pt->num_raster_tiles : a.rtx * a.rty;
-    VR_HIP(hipEventRecord(t->ev_raster_begin, s));
-    t->raster_begin_recorded = true;
+    // vr_terrain_prepare's start hint: "the context's stream has reached this tile pass".  With dispatch-stamped events that
+    // is the stop event of whatever ran last on the stream (the previous frame's lighting pass); else an explicit record.
+    if (ctx->dispatch_events && ctx->last_stop) { t->start_hint = ctx->last_stop; t->raster_begin_recorded = true; }
+    else { VR_HIP(hipEventRecord(t->ev_raster_begin, s)); t->start_hint = t->ev_raster_begin; t->raster_begin_recorded = true; }
+    hipEvent_t pass_stop = nullptr;
     if (grid > 0) {
         VrKernelScope ks(ctx, VR_K_RASTER, s, true);
         const int32_t* tiles = g.d_tile_order;            // this frame's tiles, longest bins first (k_scan)
@@ -1377,8 +1380,10 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
+        if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
     }
-    VR_HIP(hipEventRecord(g.ev_raster_done, s));
+    if (pass_stop) g.raster_done = pass_stop;
+    else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; }
     g.raster_recorded = true;
     VR_HIP(hipGetLastError());
     return VR_OK;

@@ -549,7 +549,7 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
     // behind whatever the context's stream did to the terrain (heights)
     if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_main_dep, 0)); t->main_dep_pending = false; }
     GeoSet& g = t->sets[t->cur ^ 1];                               // the set no tile pass in flight is reading
-    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, g.ev_raster_done, 0));
+    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, g.raster_done, 0));
     g.prepared = false;
     int rc = vr_select_launch(t, g, view, max_height, t->geo_stream);
     if (rc) return rc;

@@ -40,6 +40,10 @@ class Context:
         """Geometry stages of TerrainPass.Render on a second stream (overlaps the previous frame's lighting)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_ASYNC_GEOMETRY, int(enable)), "vr_context_set_option")
 
+    def set_dispatch_events(self, enable):
+        """Tile pass / lighting pass launched with dispatch-stamped events that double as cross-stream dependencies (default on)."""
+        check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_DISPATCH_EVENTS, int(enable)), "vr_context_set_option")
+
     def timing_enable(self, enable=True):
         check(self.lib.vr_timing_enable(self.handle, int(enable)), "vr_timing_enable")
 
