@@ -15,7 +15,7 @@ for src in B.SOURCES:
     o = os.path.join(out, src.replace(".hip", ".o"))
     per_file = [f.split("=", 1)[1] for f in extra if f.startswith(src + "=")]
     glob = [f for f in extra if "=" not in f or not f.split("=", 1)[0].endswith(".hip")]
-    subprocess.run([B._hipcc(), *B.FLAGS, *glob, *per_file, "-c", os.path.join(B.CSRC, src), "-o", o], check=True)
+    subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), *glob, *per_file, "-c", os.path.join(B.CSRC, src), "-o", o], check=True)
     objs.append(o)
 subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libvrterrain.so"), *objs, "-ldl"], check=True)
 print(os.path.join(out, "libvrterrain.so"))

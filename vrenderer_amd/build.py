@@ -18,6 +18,11 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+# The SLP vectoriser pairs the tile pass's scalar fp32 operations into v_pk_mul/add_f32, which issue no faster than two
+# scalar instructions on this part (profiles/r01_valu_issue_rates.txt) and cost register-pair moves: 4.5 % slower (A/B on one device).
+PER_FILE_FLAGS = {"vr_raster.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in ("/opt/rocm/bin/hipcc", "hipcc"):
         if c == "hipcc" or os.path.exists(c):
@@ -42,7 +47,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
