@@ -1,43 +1,44 @@
-"""Turns rocprofv3 PMC passes into profiles/<tag>_pmc_traffic.json (read by bench.py for `traffic`).
+"""Turns the rocprofv3 PMC passes collected by tools/collect_profiles.sh into the JSON files bench.py reads.
 
-Collection (separate passes, as MI355X_MICROARCH.md §HBM prescribes; on the GPU box):
-  cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <out>/pmc_fetch --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <out>/pmc_write --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
-Units/corrections: both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes
-of a wide (16 B/lane) coalesced streaming read, so it is doubled for k_deferred (whose reads are all
-16 B/lane).  k_raster's reads are narrow gathers: its FETCH_SIZE is reported uncorrected (lower bound).
+  python tools/summarize_pmc.py traffic FETCH.csv WRITE.csv OUT.json     # HBM bytes per launch (roofline.traffic)
+  python tools/summarize_pmc.py sq SQA.csv SQB.csv OUT.json             # SQ counters per launch (roofline_valu)
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for the lighting passes
+(k_deferred, k_deferred_tiled: all their reads are 16 B/lane).  k_raster's reads are narrow gathers: its FETCH_SIZE is
+reported uncorrected (a lower bound).  WRITE_SIZE reads 16-B-per-lane streaming stores exactly.
 """
 import collections
 import csv
-import glob
 import json
 import sys
 
 
-def agg(pattern):
-    rows = list(csv.DictReader(open(glob.glob(pattern)[0])))
-    d = collections.defaultdict(list)
-    for r in rows:
-        d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in d.items()}
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if k.startswith("k_"):
+            d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in d.items()}
 
 
-def main(fetch_dir, write_dir, out_path):
-    f = agg(fetch_dir + "/*/*counter_collection.csv")
-    w = agg(write_dir + "/*/*counter_collection.csv")
+def main():
+    mode, a, b, out_path = sys.argv[1:5]
+    A, B = agg(a), agg(b)
     out = {}
-    for k in sorted(set(f) | set(w)):
-        if not k.startswith("k_"):
-            continue
-        name = k.split("<")[0]
-        fetch_kib, write_kib = f.get(k, 0.0), w.get(k, 0.0)
-        factor = 2.0 if name == "k_deferred" else 1.0
-        out[name] = {"FETCH_SIZE_KiB": round(fetch_kib, 1), "WRITE_SIZE_KiB": round(write_kib, 1), "fetch_correction": factor,
-                     "hbm_bytes_per_launch": int((fetch_kib * factor + write_kib) * 1024)}
+    if mode == "traffic":
+        for k in sorted(set(A) | set(B)):
+            fetch_kib, write_kib = A.get(k, {}).get("FETCH_SIZE", 0.0), B.get(k, {}).get("WRITE_SIZE", 0.0)
+            factor = 2.0 if k in ("k_deferred", "k_deferred_tiled") else 1.0
+            out[k] = {"FETCH_SIZE_KiB": round(fetch_kib, 1), "WRITE_SIZE_KiB": round(write_kib, 1), "fetch_correction": factor,
+                      "hbm_bytes_per_launch": int((fetch_kib * factor + write_kib) * 1024)}
+    else:
+        for k in sorted(set(A) | set(B)):
+            out[k] = {c: round(v, 1) for c, v in sorted({**A.get(k, {}), **B.get(k, {})}.items())}
     json.dump(out, open(out_path, "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    print(json.dumps({k: out[k] for k in out if k in ("k_raster", "k_deferred", "k_deferred_tiled")}, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main()

@@ -53,8 +53,10 @@ struct Surface {
     float occlusion, alpha, a2, kk, gv;
 };
 
+// known_wp: the world position, when the caller has already reconstructed it (the tiled pass's tile box)
 __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
-                                                  uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23)
+                                                  uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
+                                                  const float* known_wp = nullptr)
 {
 #pragma clang fp contract(fast)
     Surface s;
@@ -66,27 +68,30 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
     s.N[2] = vr_max((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f);
     const float rough = vr_max((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
     s.E[0] = vr_half_to_float(e01 & 0xffffu); s.E[1] = vr_half_to_float(e01 >> 16); s.E[2] = vr_half_to_float(e23 & 0xffffu);
-    // ReconstructWorldPosition: window -> clip -> world
-    float cx, cy;
-    {
-#pragma clang fp contract(off)
-        cx = ((float)px + 0.5f) * a.sx + -1.0f; cy = ((float)py + 0.5f) * a.sy + 1.0f;
-    }
-    float wp4[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
-    const float rw = fast_rcp(wp4[3]);
-    s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
-    if (a.exact_pos) {
-        // Far from the camera clip -> world is ill-conditioned (w = depth * c2w[11] + c2w[15] cancels to a few significant
-        // bits: at depth 0.9999 one rounding moves the point by a world unit).  A directional light does not care, a
-        // point light's distance and direction do, so with positional lights in the list the position is evaluated in the
-        // checker's exact order - no contraction, IEEE divisions (wave-uniform branch; the sun-only pass is unchanged).
-#pragma clang fp contract(off)
-        float e4[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
-        s.wp[0] = e4[0] / e4[3]; s.wp[1] = e4[1] / e4[3]; s.wp[2] = e4[2] / e4[3];
+    if (known_wp) { s.wp[0] = known_wp[0]; s.wp[1] = known_wp[1]; s.wp[2] = known_wp[2]; }
+    else {
+        // ReconstructWorldPosition: window -> clip -> world
+        float cx, cy;
+        {
+    #pragma clang fp contract(off)
+            cx = ((float)px + 0.5f) * a.sx + -1.0f; cy = ((float)py + 0.5f) * a.sy + 1.0f;
+        }
+        float wp4[4];
+    #pragma unroll
+        for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
+        const float rw = fast_rcp(wp4[3]);
+        s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
+        if (a.exact_pos) {
+            // Far from the camera clip -> world is ill-conditioned (w = depth * c2w[11] + c2w[15] cancels to a few significant
+            // bits: at depth 0.9999 one rounding moves the point by a world unit).  A directional light does not care, a
+            // point light's distance and direction do, so with positional lights in the list the position is evaluated in the
+            // checker's exact order - no contraction, IEEE divisions (wave-uniform branch; the sun-only pass is unchanged).
+    #pragma clang fp contract(off)
+            float e4[4];
+    #pragma unroll
+            for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
+            s.wp[0] = e4[0] / e4[3]; s.wp[1] = e4[1] / e4[3]; s.wp[2] = e4[2] / e4[3];
+        }
     }
     const float d[3] = { s.wp[0] - a.cam[0], s.wp[1] - a.cam[1], s.wp[2] - a.cam[2] };
     const float dl = fast_rsq(dot3c(d[0], d[1], d[2], d[0], d[1], d[2]));
@@ -486,13 +491,105 @@ constexpr int kTileLightCap = VR_TILE_LIGHT_CAP;
 // w = 0 for a point light, 1 + half angular size for a directional one (its cos/sin/tan are then taken per pixel).
 struct TiledLight { float vec[3]; float inv_range; float color[3]; float w; };
 
+// Coarse culling, one workgroup per 128x128 macro tile (= owner tile): depth range of the tile's covered pixels -> the
+// world-space box of that frustum cell (its 8 corners) -> the lights whose sphere touches the box, in light order, as a
+// global list (count, then indices).  The 32x32 tiles of k_deferred_tiled then test a few dozen lights each instead of
+// all of them (1024 lights x 32,400 tiles x 64 B per light was most of that kernel's time at 8K).
+constexpr int kMacroTile = VR_OWNER_TILE;
+__global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
+                                                           const float* __restrict__ g_depth, int macro_x,
+                                                           const int32_t* __restrict__ owned_tiles, uint32_t* __restrict__ lists, int stride)
+{
+    __shared__ float s_min[4], s_max[4];
+    __shared__ float s_box[6];
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint32_t s_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = owned_tiles ? owned_tiles[blockIdx.x] : (int)blockIdx.x;
+    const int ty = tile / macro_x, tx = tile - ty * macro_x;
+    const int x0 = tx * kMacroTile, y0 = ty * kMacroTile;
+    uint32_t* __restrict__ list = lists + (size_t)tile * stride;
+    float dmin = 2.0f, dmax = -1.0f;
+    for (int r = 0; r < kMacroTile / 8; r++) {
+        const int py = y0 + r * 8 + (tid >> 5), px = x0 + (tid & 31) * 4;
+        if (py < a.h && px < a.w) {                                 // the frame width is a multiple of 4
+            const float4 d = *reinterpret_cast<const float4*>(g_depth + (size_t)py * a.w + px);
+            const float v[4] = { d.x, d.y, d.z, d.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = vr_min(dmin, v[k]); dmax = vr_max(dmax, v[k]); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { dmin = vr_min(dmin, __shfl_xor(dmin, off)); dmax = vr_max(dmax, __shfl_xor(dmax, off)); }
+    if (lane == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
+    if (tid == 0) s_count = 0u;
+    __syncthreads();
+    dmin = vr_min(vr_min(s_min[0], s_min[1]), vr_min(s_min[2], s_min[3]));
+    dmax = vr_max(vr_max(s_max[0], s_max[1]), vr_max(s_max[2], s_max[3]));
+    if (!(dmin <= dmax)) { if (tid == 0) list[0] = 0u; return; }    // nothing covered: every tile inside skips its lights
+    if (wave == 0) {
+        // the cell's 8 corners (window edges of the tile x {dmin, dmax}), reconstructed in the shading pass's exact order
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f }, far2 = 0.0f;
+        if (lane < 8) {
+#pragma clang fp contract(off)
+            const float wx = (float)(lane & 1 ? min(x0 + kMacroTile, a.w) : x0), wy = (float)(lane & 2 ? min(y0 + kMacroTile, a.h) : y0);
+            const float depth = lane & 4 ? dmax : dmin;
+            const float cx = wx * a.sx + -1.0f, cy = wy * a.sy + 1.0f;
+            float e4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lo[c] = hi[c] = e4[c] / e4[3]; const float dc = lo[c] - a.cam[c]; far2 += dc * dc; }
+        }
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], __shfl_xor(lo[c], off)); hi[c] = vr_max(hi[c], __shfl_xor(hi[c], off)); }
+            far2 = vr_max(far2, __shfl_xor(far2, off));
+        }
+        // Far from the camera clip -> world loses bits (w cancels): a pixel's reconstructed position and these corners may
+        // each be off by ~1.5e-3 of their distance (2.4 units at 1600).  The pad covers both.
+        const float pad = 4.0e-3f * sqrtf(far2) + 1.0e-2f;
+        if (lane == 0) { for (int c = 0; c < 3; c++) { s_box[c] = lo[c] - pad; s_box[3 + c] = hi[c] + pad; } }
+    }
+    __syncthreads();
+    const float lo[3] = { s_box[0], s_box[1], s_box[2] }, hi[3] = { s_box[3], s_box[4], s_box[5] };
+    for (int base = 0; base < num_lights; base += 256) {
+        const int li = base + tid;
+        bool keep = false;
+        if (li < num_lights) {
+            const DevLight L = lights[li];
+            if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) keep = true;
+            else {
+                float d2 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const float d = vr_max(vr_max(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
+                const float r = 1.0f / L.inv_range;
+                keep = d2 <= (r * r) * 1.0001f;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = s_count;
+        for (int w = 0; w < wave; w++) before += s_wave_count[w];
+        const uint32_t total = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+        if (keep) list[1u + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)li;
+        __syncthreads();
+        if (tid == 0) s_count += total;
+        __syncthreads();
+    }
+    if (tid == 0) list[0] = s_count;
+}
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
                                                          const float* __restrict__ g_depth, const uint32_t* __restrict__ g_diff,
                                                          const uint32_t* __restrict__ g_spec, const uint2* __restrict__ g_nrm,
                                                          const uint2* __restrict__ g_emi, uint2* __restrict__ out,
                                                          const float* __restrict__ lut_g, const int32_t* __restrict__ owned_tiles,
-                                                         uint32_t* __restrict__ overflow_flag)
+                                                         uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ macro_lists,
+                                                         int macro_x, int macro_stride)
 {
 #pragma clang fp contract(fast)
     __shared__ float lut[256];
@@ -542,16 +639,29 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
     // ---- 1. tile bounding box in world space (background pixels receive no light: albedo = F0 = N = 0)
     const float big = 3.0e38f;
     float lo[3] = { big, big, big }, hi[3] = { -big, -big, -big };
+    float wpos[4][3];                                                // the pixels' world positions, reused by the shading below
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        float* pos = wpos[k];
+        pos[0] = pos[1] = pos[2] = 0.0f;
         if (!(inside && depth[k] < 1.0f)) continue;
-        const float cx = ((float)(px0 + k) + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
-        float w4[4];
+        if (a.exact_pos) {       // the positions the shading below uses (decode_surface): far pixels are ill-conditioned
+#pragma clang fp contract(off)
+            const float cx = ((float)(px0 + k) + 0.5f) * a.sx + -1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+            float e4[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) w4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth[k] * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
-        const float rw = fast_rcp(w4[3]);
+            for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth[k] * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
+            pos[0] = e4[0] / e4[3]; pos[1] = e4[1] / e4[3]; pos[2] = e4[2] / e4[3];
+        } else {
+            const float cx = ((float)(px0 + k) + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
+            float w4[4];
 #pragma unroll
-        for (int c = 0; c < 3; c++) { const float v = w4[c] * rw; lo[c] = vr_min(lo[c], v); hi[c] = vr_max(hi[c], v); }
+            for (int j = 0; j < 4; j++) w4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth[k] * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
+            const float rw = fast_rcp(w4[3]);
+            pos[0] = w4[0] * rw; pos[1] = w4[1] * rw; pos[2] = w4[2] * rw;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], pos[c]); hi[c] = vr_max(hi[c], pos[c]); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -570,13 +680,15 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
 #pragma unroll
     for (int c = 0; c < 3; c++) { const float pad = 1e-4f * vr_max(fabsf(lo[c]), fabsf(hi[c])) + 1e-6f; lo[c] -= pad; hi[c] += pad; }
 
-    // ---- 2. cull, 256 lights per round, list kept in light order
-    for (int base = 0; base < num_lights && any_covered; base += 256) {
+    // ---- 2. cull the macro tile's list (k_light_macro_cull), 256 lights per round, list kept in light order
+    const uint32_t* __restrict__ mlist = macro_lists + (size_t)((py / kMacroTile) * macro_x + (px0 / kMacroTile)) * macro_stride;
+    const int n_macro = any_covered ? (int)mlist[0] : 0;       // (py, px0: this lane's pixel; the whole 32x32 tile lies in one macro tile)
+    for (int base = 0; base < n_macro; base += 256) {
         const int li = base + tid;
         bool keep = false;
         DevLight L;
-        if (li < num_lights) {
-            L = lights[li];
+        if (li < n_macro) {
+            L = lights[mlist[1 + li]];
             if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) keep = true;
             else {
                 float d2 = 0.0f;
@@ -614,7 +726,8 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
     uint32_t o[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const Surface s = decode_surface(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1]);
+        // (a background pixel's position is never used: albedo = F0 = N = 0 and it receives no light)
+        const Surface s = decode_surface(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], wpos[k]);
         float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
         if (depth[k] < 1.0f) {
             for (uint32_t i = 0; i < n; i++) {
@@ -663,6 +776,16 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     for (int i = 0; i < num_lights; i++) if (ctx->h_lights[i].type != VR_LIGHT_DIRECTIONAL) a.exact_pos = 1;
     const bool packed = part != nullptr;
     VR_REQUIRE(gb->w % 4 == 0, "the tiled pass needs a frame width that is a multiple of 4");
+    // coarse lists: one per 128x128 macro tile, count + up to num_lights indices
+    const int macro_x = (gb->w + kMacroTile - 1) / kMacroTile, macro_y = (gb->h + kMacroTile - 1) / kMacroTile;
+    const int stride = num_lights + 1;
+    const size_t words = (size_t)macro_x * macro_y * stride;
+    if (words > ctx->macro_list_words) {
+        VR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_macro_lists); ctx->d_macro_lists = nullptr; ctx->macro_list_words = 0;
+        VR_HIP(hipMalloc(&ctx->d_macro_lists, words * sizeof(uint32_t)));
+        ctx->macro_list_words = words;
+    }
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
     if (packed) {
         const PartTables* pt = nullptr;
@@ -671,16 +794,21 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         const int sub = VR_OWNER_TILE / kLightTile;
-        if (pt->num_owned > 0)
+        if (pt->num_owned > 0) {
+            hipLaunchKernelGGL(k_light_macro_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_macro_lists, stride);
             hipLaunchKernelGGL(k_deferred_tiled<true>, dim3((unsigned)pt->num_owned * sub * sub), dim3(256), 0, ctx->stream, a, ctx->d_lights,
                                num_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
-                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_flags);
+                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_flags, ctx->d_macro_lists, macro_x, stride);
+        }
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         const int tx = (gb->w + kLightTile - 1) / kLightTile, ty = (gb->h + kLightTile - 1) / kLightTile;
+        hipLaunchKernelGGL(k_light_macro_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_macro_lists, stride);
         hipLaunchKernelGGL(k_deferred_tiled<false>, dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
-                           (const int32_t*)nullptr, ctx->d_flags);
+                           (const int32_t*)nullptr, ctx->d_flags, ctx->d_macro_lists, macro_x, stride);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;
