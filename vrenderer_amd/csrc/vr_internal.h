@@ -181,7 +181,6 @@ struct vr_ldr_image {
 struct GeoSet {
     uint32_t* d_node_ids = nullptr;      // select outputs
     vr_instance* d_instances = nullptr;
-    uint32_t* d_sel_scratch = nullptr;   // k_select's two frontiers + selected list
     uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled

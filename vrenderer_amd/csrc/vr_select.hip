@@ -17,7 +17,7 @@
 #include <string.h>
 #include <stdlib.h>
 
-constexpr int kSelThreads = 256;
+constexpr int kSelThreads = 1024;
 constexpr int kFrontierCap = 4096;
 constexpr int kSelectedCap = 4096;   // LDS capacity == the largest max_instances (more is an error anyway)
 
@@ -95,18 +95,16 @@ __device__ __forceinline__ uint32_t node_id_of(const NodeGeom& g, int depth)
     return (uint32_t)((((uint64_t)1 << (2 * depth)) - 1) / 3) + g.iz * (1u << depth) + g.ix;
 }
 
-// One small workgroup (4 waves, < 100 B of LDS): the frontiers and the selected list live in a 48 KiB global scratch
-// that stays in L2, so the kernel fits beside the tile pass's workgroups on any CU and starts at once (with the lists in
-// LDS it needed 48 KiB on one CU and waited for two tile-pass workgroups to retire: 60-200 us of queueing per frame).
 __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* __restrict__ node_ids,
                                                         vr_instance* __restrict__ inst, uint32_t* __restrict__ counters,
-                                                        const float2* __restrict__ heights, uint32_t* __restrict__ scratch)
+                                                        const float2* __restrict__ heights)
 {
-    uint32_t* const frontier0 = scratch, * const frontier1 = scratch + kFrontierCap, * const selected = scratch + 2 * kFrontierCap;
+    __shared__ uint32_t frontier[2][kFrontierCap];
+    __shared__ uint32_t selected[kSelectedCap];
     __shared__ uint32_t n_front[2], n_sel, overflow;
     const int tid = threadIdx.x;
     const int L = a.num_lods;
-    if (tid < a.num_surfaces) frontier0[tid] = (uint32_t)tid << kPathBits;      // every quadtree's root
+    if (tid < a.num_surfaces) frontier[0][tid] = (uint32_t)tid << kPathBits;      // every quadtree's root
     if (tid == 0) { n_front[0] = (uint32_t)a.num_surfaces; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
     __syncthreads();
 
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         const int depth = L - lod;
         const uint32_t n = n_front[cur];
         for (uint32_t i = tid; i < n; i += kSelThreads) {
-            const uint32_t entry = (cur ? frontier1 : frontier0)[i];
+            const uint32_t entry = frontier[cur][i];
             const uint32_t path = entry & ((1u << kPathBits) - 1u);
             const int surf = (int)(entry >> kPathBits);
             NodeGeom g = node_from_path(a, path, depth, surf);
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
                 uint32_t slot = atomicAdd(&n_front[cur ^ 1], 4u);
                 if (slot + 4u <= (uint32_t)kFrontierCap) {
 #pragma unroll
-                    for (uint32_t c = 0; c < 4u; c++) (cur ? frontier0 : frontier1)[slot + c] = ((uint32_t)surf << kPathBits) | (path << 2) | c;
+                    for (uint32_t c = 0; c < 4u; c++) frontier[cur ^ 1][slot + c] = ((uint32_t)surf << kPathBits) | (path << 2) | c;
                 } else overflow = 1u;
             }
         }
@@ -206,7 +204,7 @@ int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_he
     a.nodes_per_tree = (uint32_t)((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
     VrKernelScope ks(t->ctx, VR_K_SELECT, stream);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, stream, a, g.d_node_ids, g.d_instances, g.d_counters,
-                       (const float2*)t->d_node_heights, g.d_sel_scratch);
+                       (const float2*)t->d_node_heights);
     VR_HIP(hipGetLastError());
     g.have_selection = true;
     return VR_OK;
@@ -452,7 +450,6 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_ALLOC(g.d_node_ids, mi * sizeof(uint32_t));
         VR_ALLOC(g.d_instances, mi * sizeof(vr_instance));
         VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
-        VR_ALLOC(g.d_sel_scratch, (2 * kFrontierCap + kSelectedCap) * sizeof(uint32_t));
         VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
         VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
         VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * 9 * sizeof(uint4));
@@ -492,7 +489,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
     for (GeoSet& g : t->sets) {
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
-        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_sel_scratch); (void)hipFree(g.d_verts);
+        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
         (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
         (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
     }
