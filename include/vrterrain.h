@@ -316,6 +316,7 @@ VR_API void   vr_ldr_image_destroy(vr_ldr_image* im);
 VR_API void*  vr_ldr_image_device_ptr(vr_ldr_image* im);
 VR_API size_t vr_ldr_image_capacity(vr_ldr_image* im);
 VR_API int    vr_ldr_image_download(vr_ldr_image* im, void* host, size_t bytes);   /* synchronous; bytes <= capacity */
+VR_API int    vr_ldr_image_upload(vr_ldr_image* im, const void* host, size_t bytes);
 
 /* ---- multi-GPU frame assembly (new) -------------------------------- */
 VR_API int    vr_partition_num_tiles(int32_t width, int32_t height, const vr_partition* part,

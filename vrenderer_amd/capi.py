@@ -134,7 +134,7 @@ EXPORTS = [
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_prepare", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
-    "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_ldr_image_create", "vr_ldr_image_destroy", "vr_ldr_image_device_ptr", "vr_ldr_image_capacity", "vr_ldr_image_download", "vr_deferred_light", "vr_deferred_light_tiled", "vr_deferred_tiled_status", "vr_partition_num_tiles",
+    "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_ldr_image_create", "vr_ldr_image_destroy", "vr_ldr_image_device_ptr", "vr_ldr_image_capacity", "vr_ldr_image_download", "vr_ldr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_deferred_tiled_status", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile",
     "vr_shadow_default_params", "vr_shadow_view_setup", "vr_deferred_light_shadowed",
     "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
@@ -209,6 +209,7 @@ def load_library():
         "vr_ldr_image_device_ptr": (vp, [vp]),
         "vr_ldr_image_capacity": (C.c_size_t, [vp]),
         "vr_ldr_image_download": (C.c_int, [vp, vp, C.c_size_t]),
+        "vr_ldr_image_upload": (C.c_int, [vp, vp, C.c_size_t]),
         "vr_deferred_light": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),
                                         vp, P(Partition)]),
         "vr_deferred_light_tiled": (C.c_int, [vp, P(View), vp, P(Light), C.c_int32, P(C.c_float), P(C.c_float),

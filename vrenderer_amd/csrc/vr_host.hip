@@ -554,6 +554,16 @@ extern "C" VR_API int vr_ldr_image_download(vr_ldr_image* im, void* host, size_t
     return VR_OK;
 }
 
+extern "C" VR_API int vr_ldr_image_upload(vr_ldr_image* im, const void* host, size_t bytes)
+{
+    VR_REQUIRE(im && host, "NULL argument");
+    VR_REQUIRE(bytes <= im->capacity_bytes, "byte count exceeds the image");
+    VR_HIP(hipSetDevice(im->ctx->device));
+    VR_HIP(hipMemcpyAsync(im->data, host, bytes, hipMemcpyHostToDevice, im->ctx->stream));
+    VR_HIP(hipStreamSynchronize(im->ctx->stream));
+    return VR_OK;
+}
+
 // ---- screen-tile partition ----------------------------------------------
 static void owner_grid(int w, int h, int* tx, int* ty)
 {

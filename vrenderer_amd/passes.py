@@ -230,6 +230,10 @@ class LdrImage:
         check(self.ctx.lib.vr_ldr_image_download(self.handle, _vp(raw), n), "vr_ldr_image_download")
         return raw.reshape(self.height, self.width, 4) if nbytes is None else raw
 
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        check(self.ctx.lib.vr_ldr_image_upload(self.handle, _vp(a), a.nbytes), "vr_ldr_image_upload")
+
     def close(self):
         if self.handle:
             self.ctx.lib.vr_ldr_image_destroy(self.handle)
