@@ -22,6 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HIP multiplexes streams onto 4 hardware queues by default; the N-rank loop uses 5 (render, exchange, de-tile, two geometry
+# streams) and streams that share a queue serialise.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 DEFERRED_BYTES_PER_PX = 36     # 28 B G-buffer read + 8 B RGBA16F write
 GBUFFER_BYTES_PER_PX = 28      # G-buffer fill, per covered pixel
@@ -136,6 +140,8 @@ def main():
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not build frame i+1's geometry ahead (vr_terrain_prepare) under frame i's tile pass")
+    ap.add_argument("--prepare-depth", type=int, default=2, choices=[1, 2],
+                    help="how many frames ahead vr_terrain_prepare builds geometry (three geometry sets, one stream each: two chains in flight)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: run the all-gather + de-tile of frame i on the render stream instead of overlapping it with frame i+1")
     ap.add_argument("--verify", action="store_true", help="after timing, compare the assembled frame with an unsplit render")
@@ -337,8 +343,13 @@ def main():
         else:
             deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p, shadow_map=shadow_map)
 
+    def prepare_ahead(i, p):
+        tp.Prepare(views[(i + 1) % 120], rt, rp, p)          # frame i+1's geometry is built under frame i's tile pass
+        if args.prepare_depth > 1:
+            tp.Prepare(views[(i + 2) % 120], rt, rp, p)      # ... and frame i+2's: a second chain in flight (a no-op for a frame already prepared)
+
     def step(i):
-        v, vnext = views[i % 120], views[(i + 1) % 120]
+        v = views[i % 120]
         if shadow_map is not None:                  # every rank renders the whole (small) shadow map
             shadow_map.SetupForPlanarViewStable(lights[0], v)
             shadow_map.RenderTerrain(tp)
@@ -348,7 +359,7 @@ def main():
                 main_stream.wait_event(emu_tm_done[i % 2])         # the packed tiles of two frames ago have been consumed
             tp.Render(v, v, rt, rp, part)
             if not args.no_prepare and shadow_map is None:
-                tp.Prepare(vnext, rt, rp, part)      # frame i+1's geometry is built under frame i's tile pass
+                prepare_ahead(i, part)
             light(v, out_img, part)
             if emu and emu_ldr:
                 emu_render_done[i % 2].record(main_stream)
@@ -364,7 +375,7 @@ def main():
         main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
         tp.Render(v, v, rt, rp, part)
         if not args.no_prepare and shadow_map is None:
-            tp.Prepare(vnext, rt, rp, part)
+            prepare_ahead(i, part)
         light(v, hdr_bufs[b], part)
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):

@@ -1287,20 +1287,30 @@ def test_random_texture_fuzz_bit_exact(oracle, gpu_ctx):
             tp.close(); ot.close()
 
 
-def test_api_sequence_fuzz(scene256, oracle, gpu_ctx):
-    """A random sequence of the frame-loop calls (Render, Prepare for the same or another view, lock-view renders, a rank's
-    partition, SetHeight toggles, stand-alone NodeSelect): every frame must still equal the oracle's. Exercises the
-    double-buffered geometry sets, the prepared-geometry matching and the cross-stream dependencies."""
+def test_api_sequence_fuzz(oracle, gpu_ctx):
+    """A random sequence of the frame-loop calls (Render, Prepare for the same or other views - up to two frames ahead -,
+    prepared frames consumed later, lock-view renders, a rank's partition with and without a prepared set, SetHeight toggles,
+    stand-alone NodeSelect, a shadow-map render in between): every frame must still equal the oracle's.  Exercises the three
+    rotating geometry sets and their streams, the prepared-geometry matching, the per-partition tables and the
+    cross-stream dependencies.  The very first call on a fresh terrain is a Prepare with a partition."""
     rng = np.random.default_rng(424242)
-    ot, tp = scene256["ot"], scene256["tp"]
+    size = 256
+    hmap = oracle.synth_heightmap(size)
+    alb = oracle.synth_albedo(size, hmap)
+    ot = oracle.OracleTerrain(params(size), hmap, alb)
+    tp = vr.TerrainPass(gpu_ctx, params(size)).Init(hmap, alb)          # fresh: nothing cached for any partition yet
     w, h = 320, 180
     views = [vr.make_view(*scaled_camera(c, 256), w, h) for c in CAMERAS]
     rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    sm = vr.CascadedShadowMap(gpu_ctx, vr.default_shadow_params(256.0, resolution=256))
     heights = False
     can_lock = False
+    ops = ["render", "render", "prepare_render", "prepare_other", "prepare_two", "lock", "part", "part_prepared", "height", "select", "shadow"]
     try:
-        for step in range(70):
-            op = rng.choice(["render", "render", "prepare_render", "prepare_other", "lock", "part", "height", "select"])
+        first = True
+        for step in range(90):
+            op = "part_prepared" if first else rng.choice(ops)
+            first = False
             v = views[int(rng.integers(len(views)))]
             if op == "height":
                 heights = not heights
@@ -1313,13 +1323,26 @@ def test_api_sequence_fuzz(scene256, oracle, gpu_ctx):
                 assert n_g == n_o and np.array_equal(ids_g, ids_o) and np.array_equal(inst_g, inst_o), (step, op)
                 can_lock = False                         # a stand-alone NodeSelect is not part of the reference's Render state
                 continue
-            part = vr.Partition(int(rng.integers(0, 3)), 3) if op == "part" else None
+            if op == "shadow":                           # a depth-only render of another size between two frames (Renderer.cpp:333-372)
+                lv = sm.SetupForPlanarViewStable(vr.reference_sun(), v)
+                sm.Clear(); sm.RenderTerrain(tp)
+                gb_l = oracle.GBufferHost(256, 256)
+                ot.render(lv, gb_l, vr.default_render_params(400.0, depth_only=1))
+                assert np.array_equal(sm.download_depth().view(np.uint32), gb_l.depth.view(np.uint32)), (step, op)
+                can_lock = False
+                continue
+            part = vr.Partition(int(rng.integers(0, 3)), 3) if op in ("part", "part_prepared") else None
             lock = op == "lock" and can_lock
             rp = vr.default_render_params(400.0, assume_cleared=1, lock_view=int(lock))
-            if op == "prepare_render":
+            if op in ("prepare_render", "part_prepared"):
                 tp.Prepare(v, rt, rp, part)
             elif op == "prepare_other":
                 tp.Prepare(views[int(rng.integers(len(views)))], rt, rp, part)
+            elif op == "prepare_two":                    # two frames ahead, in either order, one of them this frame's view
+                other = views[int(rng.integers(len(views)))]
+                for pv in ((v, other) if rng.integers(2) else (other, v)):
+                    tp.Prepare(pv, rt, rp, part)
+                tp.Prepare(v, rt, rp, part)              # naming a prepared frame again is a no-op
             gb_o = oracle.GBufferHost(w, h)
             n_o = ot.render(v, gb_o, rp, part)
             if part is not None:
@@ -1330,8 +1353,7 @@ def test_api_sequence_fuzz(scene256, oracle, gpu_ctx):
             _assert_gbuffer_equal(gb_o, planes, f"step {step} ({op}, heights {heights}, lock {lock})")
             can_lock = True
     finally:
-        ot.set_height(False); tp.SetHeight(False)
-        rt.close()
+        sm.close(); rt.close(); tp.close(); ot.close()
 
 
 def test_shadow_fuzz(scene256, oracle, gpu_ctx):

@@ -176,8 +176,9 @@ struct vr_ldr_image {
     size_t capacity_bytes;
 };
 
-// Everything one frame's geometry stages produce and its tile pass consumes.  Two sets alternate so
-// that the geometry of frame N+1 can be built while the tile pass of frame N still reads its own.
+// Everything one frame's geometry stages produce and its tile pass consumes.  Three sets rotate: the tile pass of
+// frame N reads one while the geometry of frames N+1 and N+2 is built in the other two (vr_terrain_prepare).
+constexpr int kGeoSets = 3;
 struct GeoSet {
     uint32_t* d_node_ids = nullptr;      // select outputs
     vr_instance* d_instances = nullptr;
@@ -197,8 +198,13 @@ struct GeoSet {
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
     hipEvent_t raster_done = nullptr;    // what the geometry stream waits on before reusing this set: ev_raster_done, or the tile pass's own stop event
     bool raster_recorded = false, have_selection = false;
+    // The geometry stream this set's last chain ran on (the terrain's two streams take turns, so that two prepared
+    // frames have their latency-bound chains in flight at once).
+    hipStream_t stream = nullptr;
+    bool main_dep_pending = false;       // the context's stream changed the terrain (node heights): wait for ev_main_dep first
     // vr_terrain_prepare: geometry already built for exactly these inputs
     bool prepared = false;
+    uint64_t prep_serial = 0;            // order of the vr_terrain_prepare calls (the oldest prepared set is evicted first)
     vr_view prep_view; vr_render_params prep_rp; int prep_w = 0, prep_h = 0, prep_rank = 0, prep_world = 0;
 };
 
@@ -211,8 +217,14 @@ struct vr_terrain {
     uint8_t* d_height = nullptr; uint8_t* d_albedo = nullptr;
     uint32_t extra_vert_cap = 0, hard_cap = 0;
     size_t bin_capacity = 0;
-    GeoSet sets[2];
+    GeoSet sets[kGeoSets];
     int cur = 0;                            // set of the most recent select / render
+    uint64_t prep_counter = 0;
+    // Two geometry streams, taken in turns by successive chains.  Not one per set: HIP multiplexes streams onto 4 hardware
+    // queues by default (GPU_MAX_HW_QUEUES), and a frame loop with an exchange stage already uses 2-3 of its own; streams
+    // that share a queue serialise (measured: a fifth stream cost the N = 8 rank emulation 0.23 -> 0.39 ms per frame).
+    hipStream_t geo_streams[2] = { nullptr, nullptr };
+    unsigned geo_turn = 0;
     // QuadTree::SetHeight results: (position.y, extents.y) per node id; m_HeightLoaded
     float2* d_node_heights = nullptr;
     uchar2* d_minmax = nullptr;          // raw (min, max) bytes per node of one surface: scratch of the mip-style SetHeight
@@ -222,9 +234,9 @@ struct vr_terrain {
     // Geometry stream: select / vertex / setup / bins depend only on the view, so they run on their own
     // stream and overlap whatever the context's stream is doing (the lighting pass of the previous frame,
     // or - after vr_terrain_prepare - its tile pass); the tile pass on the context's stream waits for them.
-    hipStream_t geo_stream = nullptr;
+    hipEvent_t ev_sel_copy = nullptr;      // lock_view: the source set's selection is complete
     hipEvent_t ev_main_dep = nullptr, ev_raster_begin = nullptr;   // ev_raster_begin: the context's stream reached the last tile pass
-    bool main_dep_pending = false, raster_begin_recorded = false;
+    bool raster_begin_recorded = false;
     hipEvent_t start_hint = nullptr;        // vr_terrain_prepare starts its geometry behind this: ev_raster_begin, or the previous lighting pass's stop event
 };
 
@@ -234,6 +246,7 @@ vr_context* vr_tonemap_context(vr_tonemap* tm);
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
                           DevTex* out, uint8_t** out_mem);
 int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream);
+int vr_terrain_pick_set(vr_terrain* t);
 // tables of (w, h, part); part == NULL is the whole frame as rank 0 of 1
 int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out);
 // any cached table set of (w, h, world): the slot table does not depend on the rank

@@ -1247,19 +1247,25 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
                            const RasterArgs& a, const PartTables* pt)
 {
     vr_context* ctx = t->ctx;
-    hipStream_t s = ctx->stream, gs = t->geo_stream;
+    // this chain's stream: the terrain's two geometry streams take turns.  Whatever the set did before on the other one
+    // is ordered by the events below (its tile pass waited for its geometry, and this chain waits for that tile pass).
+    g.stream = t->geo_streams[t->geo_turn++ & 1u];
+    hipStream_t s = ctx->stream, gs = g.stream;
     if (!ctx->async_geometry) {          // single-stream mode: order the geometry behind everything queued so far
         VR_HIP(hipEventRecord(t->ev_main_dep, s));
-        t->main_dep_pending = true;
+        g.main_dep_pending = true;
     }
     // after the tile pass that last read this set, and after anything the context's stream did to the terrain
     if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.raster_done, 0));
-    if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); t->main_dep_pending = false; }
+    if (g.main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); g.main_dep_pending = false; }
     int rc;
     if (selection_from == nullptr) {                                   // TerrainPass.cpp:173-190
         if ((rc = vr_select_launch(t, g, view, rp->max_height, gs))) return rc;
     } else if (selection_from != &g) {
-        // lockView: keep the selection of the last unlocked frame (TerrainPass.cpp:191-197); it lives in the other set
+        // lockView: keep the selection of the last unlocked frame (TerrainPass.cpp:191-197); it lives in another set, whose
+        // select ran on that set's stream
+        VR_HIP(hipEventRecord(t->ev_sel_copy, selection_from->stream));
+        VR_HIP(hipStreamWaitEvent(gs, t->ev_sel_copy, 0));
         VR_HIP(hipMemcpyAsync(g.d_node_ids, selection_from->d_node_ids, (size_t)t->p.max_instances * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
         VR_HIP(hipMemcpyAsync(g.d_instances, selection_from->d_instances, (size_t)t->p.max_instances * sizeof(vr_instance), hipMemcpyDeviceToDevice, gs));
         VR_HIP(hipMemcpyAsync(g.d_counters, selection_from->d_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
@@ -1304,6 +1310,12 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     return VR_OK;
 }
 
+static bool prepared_matches(const GeoSet& g, const vr_view* view, const vr_render_params* rp, int w, int h, const RasterArgs& a)
+{
+    return memcmp(&g.prep_view, view, sizeof(vr_view)) == 0 && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only
+        && !g.prep_rp.wireframe == !rp->wireframe && g.prep_w == w && g.prep_h == h && g.prep_rank == a.rank && g.prep_world == a.world;
+}
+
 static int check_render_inputs(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp)
 {
     VR_REQUIRE(t && view && gb && rp, "NULL argument");
@@ -1324,15 +1336,19 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
     if (a.world > 1 && (rc = vr_partition_tables(t->ctx, gb->w, gb->h, part, &pt))) return rc;
-    GeoSet& g = t->sets[t->cur ^ 1];
+    // already prepared for exactly these inputs (a caller may name the same future frame twice): nothing to do
+    for (GeoSet& p : t->sets)
+        if (p.prepared && prepared_matches(p, view, rp, gb->w, gb->h, a)) return VR_OK;
+    GeoSet& g = t->sets[vr_terrain_pick_set(t)];
     g.prepared = false;
     // Start when the context's stream starts the tile pass queued last: the host runs frames ahead of the
     // device, and without this the geometry would become runnable one pass earlier and share the device
     // with the previous frame's lighting pass (bandwidth-bound) instead of with a tile pass (which leaves
     // half of every CU's wave slots free).
-    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, t->start_hint, 0));
+    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_streams[t->geo_turn & 1u], t->start_hint, 0));   // (the stream launch_geometry takes next)
     if ((rc = launch_geometry(t, g, nullptr, view, rp, a, pt))) return rc;
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
+    g.prep_serial = ++t->prep_counter;
     return VR_OK;
 }
 
@@ -1350,17 +1366,21 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
     if (a.world > 1 && (rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt))) return rc;
 
-    GeoSet& g = t->sets[t->cur ^ 1];
+    // a set prepared for exactly this frame, else a free one (the oldest prepared set is given up if all are taken)
+    int gi = -1;
+    if (!rp->lock_view)
+        for (int i = 0; i < kGeoSets; i++)
+            if (i != t->cur && t->sets[i].prepared && prepared_matches(t->sets[i], view, rp, gb->w, gb->h, a)) { gi = i; break; }
+    const bool use_prepared = gi >= 0;
+    if (!use_prepared) gi = vr_terrain_pick_set(t);
+    GeoSet& g = t->sets[gi];
     const GeoSet& last = t->sets[t->cur];
-    const bool use_prepared = g.prepared && !rp->lock_view && memcmp(&g.prep_view, view, sizeof(vr_view)) == 0
-                           && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only && !g.prep_rp.wireframe == !rp->wireframe
-                           && g.prep_w == gb->w && g.prep_h == gb->h && g.prep_rank == a.rank && g.prep_world == a.world;
     g.prepared = false;
     if (!use_prepared) {
         const GeoSet* sel = (rp->lock_view && last.have_selection) ? &last : nullptr;
         if ((rc = launch_geometry(t, g, sel, view, rp, a, pt))) return rc;
     }
-    t->cur ^= 1;
+    t->cur = gi;
     VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));                    // the tile pass consumes verts + bins
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;

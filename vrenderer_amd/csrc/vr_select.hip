@@ -391,7 +391,7 @@ extern "C" VR_API int vr_terrain_update_heights(vr_terrain* t, int enable)
     VR_HIP(hipGetLastError());
     // NodeSelect runs on the geometry stream: make it see these results
     VR_HIP(hipEventRecord(t->ev_main_dep, t->ctx->stream));
-    t->main_dep_pending = true;
+    for (GeoSet& g : t->sets) g.main_dep_pending = true;
     t->height_loaded = true;
     return VR_OK;
 }
@@ -469,9 +469,11 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         // what delays these small kernels is LDS space on the CUs, not queue arbitration)
         int least = 0, greatest = 0;
         VR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        VR_HIP(hipStreamCreateWithPriority(&t->geo_stream, hipStreamNonBlocking, least));
+        for (hipStream_t& gs : t->geo_streams) VR_HIP(hipStreamCreateWithPriority(&gs, hipStreamNonBlocking, least));
+        for (GeoSet& g : t->sets) g.stream = t->geo_streams[0];
     }
     VR_HIP(hipEventCreateWithFlags(&t->ev_main_dep, hipEventDisableTiming));
+    VR_HIP(hipEventCreateWithFlags(&t->ev_sel_copy, hipEventDisableTiming));
     VR_HIP(hipEventCreateWithFlags(&t->ev_raster_begin, hipEventDisableTiming));
     *out = t;
     t = nullptr;                 // released to the caller
@@ -483,8 +485,9 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    if (t->geo_stream) { (void)hipStreamSynchronize(t->geo_stream); (void)hipStreamDestroy(t->geo_stream); }
+    for (hipStream_t gs : t->geo_streams) if (gs) { (void)hipStreamSynchronize(gs); (void)hipStreamDestroy(gs); }
     if (t->ev_main_dep) (void)hipEventDestroy(t->ev_main_dep);
+    if (t->ev_sel_copy) (void)hipEventDestroy(t->ev_sel_copy);
     if (t->ev_raster_begin) (void)hipEventDestroy(t->ev_raster_begin);
     for (GeoSet& g : t->sets) {
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
@@ -528,13 +531,26 @@ extern "C" VR_API int vr_terrain_download_mip(vr_terrain* t, int which, int leve
 static int read_counters(vr_terrain* t, uint32_t* count)
 {
     uint32_t c[4] = { 0, 0, 0, 0 };
-    VR_HIP(hipStreamSynchronize(t->geo_stream));          // selection and bins are produced on the geometry stream
+    VR_HIP(hipStreamSynchronize(t->sets[t->cur].stream)); // selection and bins are produced on the set's geometry stream
     VR_HIP(hipMemcpyAsync(c, t->sets[t->cur].d_counters, sizeof(c), hipMemcpyDeviceToHost, t->ctx->stream));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
     if (count) *count = c[0];
     if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
     if (c[1] & 1u) { vr_set_error("more than max_instances nodes selected (TerrainPass.cpp:238 assert)"); return VR_ERR_TOO_MANY_INSTANCES; }
     return VR_OK;
+}
+
+// The set the next select / geometry build goes to: never the current one (a tile pass may be reading it and lock_view
+// copies its selection); among the others one that holds no prepared frame, else the one prepared longest ago.
+int vr_terrain_pick_set(vr_terrain* t)
+{
+    int best = -1;
+    for (int i = 0; i < kGeoSets; i++) {
+        if (i == t->cur) continue;
+        if (!t->sets[i].prepared) return i;
+        if (best < 0 || t->sets[i].prep_serial < t->sets[best].prep_serial) best = i;
+    }
+    return best;
 }
 
 extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, float max_height, uint32_t* node_ids,
@@ -544,13 +560,15 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
     VR_HIP(hipSetDevice(t->ctx->device));
     // the selection buffers are consumed by geometry-stream kernels: order this launch behind them and
     // behind whatever the context's stream did to the terrain (heights)
-    if (t->main_dep_pending) { VR_HIP(hipStreamWaitEvent(t->geo_stream, t->ev_main_dep, 0)); t->main_dep_pending = false; }
-    GeoSet& g = t->sets[t->cur ^ 1];                               // the set no tile pass in flight is reading
-    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(t->geo_stream, g.raster_done, 0));
+    const int gi = vr_terrain_pick_set(t);                         // a set no tile pass in flight is reading
+    GeoSet& g = t->sets[gi];
+    g.stream = t->geo_streams[t->geo_turn++ & 1u];
+    if (g.main_dep_pending) { VR_HIP(hipStreamWaitEvent(g.stream, t->ev_main_dep, 0)); g.main_dep_pending = false; }
+    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(g.stream, g.raster_done, 0));
     g.prepared = false;
-    int rc = vr_select_launch(t, g, view, max_height, t->geo_stream);
+    int rc = vr_select_launch(t, g, view, max_height, g.stream);
     if (rc) return rc;
-    t->cur ^= 1;
+    t->cur = gi;
     if (!node_ids && !instances && !count) return VR_OK;       // stays asynchronous
     uint32_t n = 0;
     rc = read_counters(t, &n);
@@ -572,7 +590,7 @@ extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
 {
     VR_REQUIRE(t && out, "NULL argument");
     VR_HIP(hipSetDevice(t->ctx->device));
-    VR_HIP(hipStreamSynchronize(t->geo_stream));
+    VR_HIP(hipStreamSynchronize(t->sets[t->cur].stream));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
     const GeoSet& g = t->sets[t->cur];
     VR_HIP(hipMemcpy(out, g.d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
