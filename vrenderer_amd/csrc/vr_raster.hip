@@ -830,6 +830,33 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
     }
 }
 
+// A long triangle (one side of its box >= kWalkMin pixels - at 8K most survivors are slivers of ~100 x 7 pixels): the lanes
+// take the positions along the box's LONG axis and walk the short one, one row (two rows of a 32-pixel tile) of the tile
+// per step.  ~22 instructions per step with every lane of the long side busy, against ~28 per 8x8 block whose lanes a
+// sliver mostly misses.
+#ifndef VR_WALK_MIN
+#define VR_WALK_MIN 28
+#endif
+constexpr int kWalkMin = VR_WALK_MIN;
+template <int TILE>
+__device__ __forceinline__ void sweep_walk(unsigned long long* __restrict__ vis, int lane, int32_t e0, int32_t e1, int32_t e2, int32_t sx0, int32_t sy0,
+                                           int32_t sx1, int32_t sy1, int32_t sx2, int32_t sy2, int b0, int b1, int b2, int x0, int y0, int x1, int y1,
+                                           float z0, float dz1, float dz2, float ia, uint32_t ord)
+{
+    constexpr int PER = 64 / TILE;                               // short-axis positions covered per step: 1, or 2 for 32-pixel tiles
+    const bool horiz = (x1 - x0) >= (y1 - y0);                   // (wave-uniform)
+    const int la = lane & (TILE - 1), lb = lane / TILE;          // place on the long axis; which of the PER short-axis rows
+    const int l0 = horiz ? x0 : y0, l1 = horiz ? x1 : y1, s0 = (horiz ? y0 : x0) + lb, s1 = horiz ? y1 : x1;
+    if (la < l0 || la > l1) return;
+    const int32_t a0 = horiz ? sx0 : sy0, a1 = horiz ? sx1 : sy1, a2 = horiz ? sx2 : sy2;     // step along the long axis
+    const int32_t c0 = horiz ? sy0 : sx0, c1 = horiz ? sy1 : sx1, c2 = horiz ? sy2 : sx2;     // step along the short axis
+    int32_t v0 = (e0 - b0) + a0 * la + c0 * s0, v1 = (e1 - b1) + a1 * la + c1 * s0, v2 = (e2 - b2) + a2 * la + c2 * s0;
+    for (int sp = s0; sp <= s1; sp += PER) {
+        if ((v0 | v1 | v2) >= 0) cover_pixel<int32_t, TILE>(vis, horiz ? la : sp, horiz ? sp : la, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
+        v0 += c0 * PER; v1 += c1 * PER; v2 += c2 * PER;
+    }
+}
+
 __device__ __forceinline__ int64_t floor_div64(int64_t num, int64_t den)
 {
     if (den < 0) { num = -num; den = -den; }
@@ -908,9 +935,14 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 {
     __shared__ unsigned long long vis[TILE * TILE];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
-    __shared__ float lut[256];
     __shared__ float thr[kThrTabSize];
+    // the byte -> float tables are only needed by the variants that still read 8-bit texels (A/B builds)
+#if defined(VR_QUAD_U8) || defined(VR_ALBEDO_U8)
+    __shared__ float lut[256];
     __shared__ float r8[256];
+#else
+    const float* const lut = nullptr; const float* const r8 = nullptr;
+#endif
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
@@ -920,7 +952,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
-    lut[tid] = lut_g[tid]; thr[tid] = thr_g[tid]; r8[tid] = (float)tid / 255.0f;
+    thr[tid] = thr_g[tid];
+#if defined(VR_QUAD_U8) || defined(VR_ALBEDO_U8)
+    lut[tid] = lut_g[tid]; r8[tid] = (float)tid / 255.0f;
+#endif
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     if (a.assume_cleared && ox + TILE <= a.w && oy + TILE <= a.h) {       // interior tile of a cleared target: one constant
@@ -1067,8 +1102,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
             const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
             if (m & 8u) {
-                sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
-                                   BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
+                if (max(qx1 - qx0, qy1 - qy0) + 1 >= min(kWalkMin, TILE - 4))
+                    sweep_walk<TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
+                                     BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
+                else
+                    sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
+                                       BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
             } else {
                 const int64_t a0 = BC(A0), bb0 = BC(B0), a1 = BC(A1), bb1 = BC(B1), a2 = BC(A2), bb2 = BC(B2);
                 sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), a0 * 256, bb0 * 256, a1 * 256, bb1 * 256, a2 * 256, bb2 * 256,
