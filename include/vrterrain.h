@@ -212,15 +212,24 @@ VR_API int  vr_terrain_select(vr_terrain* t, const vr_view* view, float max_heig
 
 /* TerrainPass::Render into the G-buffer framebuffer (TerrainPass.cpp:143-232;
  * terrain_vs.hlsl, terrain_ps.hlsl; raster state TerrainPass.cpp:460-485).
- * `part` may be NULL (= whole frame on this device). */
+ * `part` may be NULL (= whole frame on this device).
+ * The call is asynchronous.  Conditions only the device can detect - more than max_instances nodes selected
+ * (VR_ERR_TOO_MANY_INSTANCES, the reference's assert at TerrainPass.cpp:238), a full bin / clipper work list
+ * (VR_ERR_OVERFLOW: triangles were dropped) - are reported by vr_terrain_num_chunks(), which waits for the frame's
+ * geometry and returns them; a host that never polls it never sees them. */
 VR_API int  vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev,
                               vr_gbuffer* gb, const vr_render_params* rp,
                               const vr_partition* part);
 /* Optional: build the view-dependent geometry (select .. bins) of an upcoming vr_terrain_render ahead of
- * time, on the terrain's geometry stream.  Called right after vr_terrain_render of frame N with frame
- * N+1's view, it overlaps frame N's tile pass (and leaves its lighting pass alone).  The next
- * vr_terrain_render uses it when view, max_height, target size and partition are identical; otherwise
- * it is discarded.  Extension; the reference has no counterpart (its frames are strictly serial). */
+ * time, on one of the terrain's two geometry streams.  Called right after vr_terrain_render of frame N with frame
+ * N+1's view, it overlaps frame N's tile pass (and leaves its lighting pass alone).  Up to two frames may be prepared
+ * ahead (N+1 and N+2: three geometry sets rotate, two chains are in flight - what keeps small frames and a rank's share
+ * of a split frame from waiting for the latency-bound chain); naming a frame that is already prepared is a no-op, a
+ * third distinct frame replaces the oldest.  A later vr_terrain_render uses a prepared set when view, max_height,
+ * target size and partition are identical; sets that are never used are simply overwritten.
+ * Extension; the reference has no counterpart (its frames are strictly serial).
+ * Note for hosts with many streams of their own: HIP maps streams onto 4 hardware queues by default and streams that
+ * share a queue serialise; the library uses the context's stream + 2.  GPU_MAX_HW_QUEUES raises the limit. */
 VR_API int  vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp,
                                const vr_partition* part);
 /* EditorParams::m_NumChunks of the last render/select (syncs the stream). */
