@@ -266,10 +266,13 @@ __device__ __forceinline__ TriDeriv tri_derivs(const TriSetup& t)
 //   6: wx0 wx1 wx2 ddeny      world x           derivative (what interp_attr computed per pixel from constants)
 //   7: wz0 wz1 wz2 inv_area   world z
 //   8: nxx nzx nxy nzy
+//   9..11: edges 1 and 2 once more as doubles - 256*A1, 256*B1, C1, 256*A2, 256*B2, C2 - for the resolve, which evaluates
+//          them in fp64 (exact: integers below 2^52) straight from the record, with no integer -> float conversion on the
+//          way; C = NaN marks a giant (|A| or |B| >= 2^23, clipped at the guard band) that must take the int64 path
 // small = every |A_i|, |B_i| <= 2^14 (edges up to 64 pixels): every edge value at a pixel of a tile the triangle
 // touches then fits 31 bits (|E(P)| <= 2^29 inside its box, + 64 pixels * 256 * (|A|+|B|) <= 2^29 to any pixel of
 // the tile), and 256*B fits 24 bits, so the tile pass runs such triangles in int32 / mad24.
-constexpr int kRecGroups = 9;
+constexpr int kRecGroups = 12;
 constexpr int32_t kSmallEdge = 1 << 14;
 
 __device__ __forceinline__ void write_tri_rec(uint4* __restrict__ dst, const TriSetup& t, const ScreenVert& s0, const ScreenVert& s1,
@@ -302,6 +305,13 @@ __device__ __forceinline__ void write_tri_rec(uint4* __restrict__ dst, const Tri
     dst[7] = make_uint4(F2U(s0.wz), F2U(s1.wz), F2U(s2.wz), F2U(t.inv_area));
     dst[8] = make_uint4(F2U(nxx), F2U(nzx), F2U(nxy), F2U(nzy));
 #undef F2U
+    {
+        const bool dok = max(max(abs(t.A1), abs(t.B1)), max(abs(t.A2), abs(t.B2))) < (1 << 23);
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        double* d = reinterpret_cast<double*>(dst + 9);
+        d[0] = (double)t.A1 * 256.0; d[1] = (double)t.B1 * 256.0; d[2] = dok ? (double)t.C1 : nan;
+        d[3] = (double)t.A2 * 256.0; d[4] = (double)t.B2 * 256.0; d[5] = dok ? (double)t.C2 : nan;
+    }
 }
 
 // Sets a triangle up against the viewport: its raster-tile rectangle, or ~0 when it is culled; a surviving
@@ -1141,13 +1151,15 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         uint32_t covered = 0;
         float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
         uint32_t prev = 0xffffffffu;
-        // the winner's record (groups 1, 2, 5..8).  The two edge functions that give the barycentrics are stepped in
-        // double precision: every term is an integer below 2^52 (|A|, |B| < 2^23, |P - vertex| < 2^28), so the arithmetic is exact
-        // and v_cvt_f32_f64 rounds the exact edge value once - the same float as (float)(int64) - in 2 instructions per
-        // edge and pixel for triangles of any size.  Giants beyond that (clipped at the guard band) take the int64 path.
+        // the winner's record (groups 5..11).  The two edge functions that give the barycentrics are evaluated and stepped in
+        // double precision: every term is an integer (or half of one) below 2^52 (|A|, |B| < 2^23, |P - vertex| < 2^28), so
+        // the arithmetic is exact and v_cvt_f32_f64 rounds the exact edge value once - the same float as (float)(int64) - in 2
+        // instructions per edge and pixel for triangles of any size, and a change of triangle costs four fp64 FMAs, no integer
+        // multiply-adds or conversions.  Giants beyond that (clipped at the guard band) take the int64 path.
         const uint4* __restrict__ rp = recs;
         bool dok = true;
         double d1 = 0.0, d2 = 0.0, sx1 = 0.0, sx2 = 0.0;
+        const double pxd = (double)gx0 + 0.5, pyd = (double)gy + 0.5;
         float ia = 0.0f, iw0 = 0.0f, iw1 = 0.0f, iw2 = 0.0f, wx0 = 0.0f, wx1 = 0.0f, wx2 = 0.0f, wz0 = 0.0f, wz1 = 0.0f, wz2 = 0.0f;
         float ddenx = 0.0f, ddeny = 0.0f, nxx = 0.0f, nzx = 0.0f, nxy = 0.0f, nzy = 0.0f;
 #pragma unroll
@@ -1160,13 +1172,14 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             if (a.depth_only) continue;
             if (low != prev) {                                    // neighbours usually share the triangle
                 rp = recs + rec_index(key_of(low), hard_first, rec_hard_base) * kRecGroups;
-                const uint4 g1 = rp[1], g2 = rp[2], g5 = rp[5], g6 = rp[6], g7 = rp[7], g8 = rp[8];
-                const int32_t A1 = (int32_t)g1.x, B1 = (int32_t)g1.y, A2 = (int32_t)g2.x, B2 = (int32_t)g2.y;
-                dok = max(max(abs(A1), abs(B1)), max(abs(A2), abs(B2))) < (1 << 23);
-                // edge values at the group's first pixel, exact in int64, then as doubles
-                const int32_t PXg = (gx0) * 256 + 128, PYg = gy * 256 + 128;
-                d1 = (double)edge_eval(A1, B1, rec_c(g1), PXg, PYg); d2 = (double)edge_eval(A2, B2, rec_c(g2), PXg, PYg);
-                sx1 = (double)A1 * 256.0; sx2 = (double)A2 * 256.0;
+                const uint4 g5 = rp[5], g6 = rp[6], g7 = rp[7], g8 = rp[8];
+                const double2 ea = reinterpret_cast<const double2*>(rp)[9], eb = reinterpret_cast<const double2*>(rp)[10],
+                              ec = reinterpret_cast<const double2*>(rp)[11];
+                // edge values at the group's first pixel centre (gx0 + 0.5, gy + 0.5) in pixel units: E = 256 A x + 256 B y + C
+                sx1 = ea.x; sx2 = eb.y;
+                d1 = __builtin_fma(sx1, pxd, __builtin_fma(ea.y, pyd, eb.x));
+                d2 = __builtin_fma(sx2, pxd, __builtin_fma(ec.x, pyd, ec.y));
+                dok = d1 == d1;                                  // NaN: a giant triangle, exact only in int64
                 iw0 = __uint_as_float(g5.x); iw1 = __uint_as_float(g5.y); iw2 = __uint_as_float(g5.z); ddenx = __uint_as_float(g5.w);
                 wx0 = __uint_as_float(g6.x); wx1 = __uint_as_float(g6.y); wx2 = __uint_as_float(g6.z); ddeny = __uint_as_float(g6.w);
                 wz0 = __uint_as_float(g7.x); wz1 = __uint_as_float(g7.y); wz2 = __uint_as_float(g7.z); ia = __uint_as_float(g7.w);

@@ -452,7 +452,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
         VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
         VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
-        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * 9 * sizeof(uint4));
+        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * 12 * sizeof(uint4));
         VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
         VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
         VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
