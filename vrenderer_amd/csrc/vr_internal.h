@@ -63,8 +63,8 @@ struct DevTex {
     // The same footprints decoded: per entry (t00, t10 - t00, t01, t11 - t01) as floats (t = byte / 255), same indexing.
     // A height tap is then one 16-byte load and 7 float operations - no byte extraction, no conversion table.
     const float4* quadf;
-    // SRGBA8 textures only: the chain decoded to linear floats, 3 per texel (12 B); level l starts at float 3 * off[l] / 4.
-    // An albedo texel is then one 12-byte load with nothing to extract or look up.
+    // SRGBA8 textures only: the chain decoded to linear floats, one float4 per texel (r, g, b, 0); level l starts at byte
+    // 4 * off[l].  An albedo texel is then one aligned 16-byte load with nothing to extract or look up, at (index << 4).
     const float* rgbf;
 };
 

@@ -683,10 +683,10 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
 #define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
     uint32_t p00, p10, p01, p11;
 #else
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    const uint32_t c3 = c * 3u;                                   // the decoded chain: 12 B per texel, levels at 3 x the byte offset
-#define LDC(i) __builtin_amdgcn_raw_buffer_load_b96(rc, ((((uint32_t)(i) << 1) + (uint32_t)(i)) << 2) + c3, 0, 0)    // 12 * i + c3, 2 VALU, any texture size
-    u32x3 p00, p10, p01, p11;
+    typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+    const uint32_t c4 = c << 2;                                   // the decoded chain: 16 B per texel, levels at 4 x the byte offset
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, ((uint32_t)(i) << 4) + c4, 0, 0)
+    u32x4c p00, p10, p01, p11;
 #endif
     float cfx, cfy;
     if (SAME) {
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 #ifdef VR_ALBEDO_U8
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.base, (short)0, (int)al.chain_bytes, 0x00020000);
 #else
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 3u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
 #endif
     for (int g = tid; g < TILE * TILE / 4; g += 256) {
         const int ly = g / (TILE / 4), lx0 = (g % (TILE / 4)) * 4;
@@ -1157,11 +1157,13 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         // instructions per edge and pixel for triangles of any size, and a change of triangle costs four fp64 FMAs, no integer
         // multiply-adds or conversions.  Giants beyond that (clipped at the guard band) take the int64 path.
         const uint4* __restrict__ rp = recs;
-        bool dok = true;
-        double d1 = 0.0, d2 = 0.0, sx1 = 0.0, sx2 = 0.0;
+        // (deliberately not initialised: the first covered pixel of a group always loads its record - prev matches no key -
+        // and zeroing 22 registers per group is 6 instructions per pixel)
+        bool dok;
+        double d1, d2, sx1, sx2;
         const double pxd = (double)gx0 + 0.5, pyd = (double)gy + 0.5;
-        float ia = 0.0f, iw0 = 0.0f, iw1 = 0.0f, iw2 = 0.0f, wx0 = 0.0f, wx1 = 0.0f, wx2 = 0.0f, wz0 = 0.0f, wz1 = 0.0f, wz2 = 0.0f;
-        float ddenx = 0.0f, ddeny = 0.0f, nxx = 0.0f, nzx = 0.0f, nxy = 0.0f, nzy = 0.0f;
+        float ia, iw0, iw1, iw2, wx0, wx1, wx2, wz0, wz1, wz2;
+        float ddenx, ddeny, nxx, nzx, nxy, nzy;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = vis[ly * TILE + lx0 + k];

@@ -65,7 +65,7 @@ __global__ void k_decode_rgbf(const uint32_t* __restrict__ src, size_t n, const 
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t p = src[i];
-        dst[i * 3 + 0] = lut[p & 255u]; dst[i * 3 + 1] = lut[(p >> 8) & 255u]; dst[i * 3 + 2] = lut[(p >> 16) & 255u];
+        reinterpret_cast<float4*>(dst)[i] = make_float4(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u], 0.0f);
     }
 }
 
@@ -99,7 +99,7 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         quadf_off = total; total += quad_dwords * sizeof(float4);
     }
     size_t rgbf_off = 0;
-    if (tb == 4) { total = (total + 255) / 256 * 256; rgbf_off = total; total += table_off / 4 * 12; }   // decoded copy of the whole chain
+    if (tb == 4) { total = (total + 255) / 256 * 256; rgbf_off = total; total += table_off / 4 * 16; }   // decoded copy of the whole chain
     VR_REQUIRE(total < ((size_t)1 << 31), "texture too large");        // texels are addressed with 32-bit byte offsets
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
