@@ -1164,9 +1164,13 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         const double pxd = (double)gx0 + 0.5, pyd = (double)gy + 0.5;
         float ia, iw0, iw1, iw2, wx0, wx1, wx2, wz0, wz1, wz2;
         float ddenx, ddeny, nxx, nzx, nxy, nzy;
+        // the group's four visibility words in one go (two 16-byte LDS reads ahead of the per-pixel control flow)
+        typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+        const u64x2v k01 = *reinterpret_cast<const u64x2v*>(&vis[ly * TILE + lx0]), k23 = *reinterpret_cast<const u64x2v*>(&vis[ly * TILE + lx0 + 2]);
+        const unsigned long long keys[4] = { k01.x, k01.y, k23.x, k23.y };
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long key = vis[ly * TILE + lx0 + k];
+            const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
             dep[k] = __uint_as_float((uint32_t)(key >> 32)); dif[k] = 0; nn0[k] = 0; nn1[k] = 0;
             if (low == 0xffffffffu || gx0 + k >= a.w) continue;
