@@ -196,7 +196,20 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # RCCL prints a version banner on stdout when the communicator comes up (at the first collective): keep stdout
+            # for the one JSON line by pointing fd 1 at stderr until then
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
 
     import vrenderer_amd as vr
     from vrenderer_amd.passes import frame_detile, frame_detile_ldr, partition_info, partition_prepare
