@@ -371,8 +371,12 @@ def main():
             if emu and emu_ldr:
                 main_stream.wait_event(emu_tm_done[i % 2])         # the packed tiles of two frames ago have been consumed
             tp.Render(v, v, rt, rp, part)
-            if not args.no_prepare and shadow_map is None:
-                prepare_ahead(i, part)
+            if not args.no_prepare:
+                if shadow_map is None:
+                    prepare_ahead(i, part)
+                else:                                # both passes of frame i+1: its shadow map's geometry, then its main view's
+                    shadow_map.PrepareTerrain(tp, lights[0], views[(i + 1) % 120])
+                    tp.Prepare(views[(i + 1) % 120], rt, rp, part)
             light(v, out_img, part)
             if emu and emu_ldr:
                 emu_render_done[i % 2].record(main_stream)

@@ -8,7 +8,7 @@ import vrenderer_amd as vr
 from tests.common import params
 from bench import flythrough_camera
 
-W, H, size = 7680, 4320, 2048
+W, H, size = int(os.environ.get("W", 7680)), int(os.environ.get("H", 4320)), 2048
 ctx = vr.Context(0); ctx.set_async_geometry(False)
 hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
 tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)

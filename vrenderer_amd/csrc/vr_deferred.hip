@@ -235,11 +235,19 @@ __device__ __forceinline__ float shadow_factor(const DeferredArgs& a, const Shad
     int xs[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) xs[i] = min(max(ix + i, 0), s.res - 1);
+    // the four texels of a footprint row are adjacent unless the footprint hangs over the map's edge: one 16-byte
+    // load per row (4-byte aligned is enough for global loads) instead of four - wave-uniform choice
+    const bool inner = __all(ix >= 0 && ix + 3 <= s.res - 1);
     float sum = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float* row_p = s.depth + (size_t)min(max(iy + j, 0), s.res - 1) * s.res;
-        const float d0 = row_p[xs[0]], d1 = row_p[xs[1]], d2 = row_p[xs[2]], d3 = row_p[xs[3]];
+        float d0, d1, d2, d3;
+        if (inner) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u d = *reinterpret_cast<const f4u*>(row_p + ix);
+            d0 = d.x; d1 = d.y; d2 = d.z; d3 = d.w;
+        } else { d0 = row_p[xs[0]]; d1 = row_p[xs[1]]; d2 = row_p[xs[2]]; d3 = row_p[xs[3]]; }
         float row = 0.0f;
         row = row + (z <= d0 ? 1.0f : 0.0f) * wgx[0];
         row = row + (z <= d1 ? 1.0f : 0.0f) * wgx[1];

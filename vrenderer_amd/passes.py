@@ -456,6 +456,14 @@ class CascadedShadowMap:
         rp = default_render_params(max_height, depth_only=1, assume_cleared=1, lock_view=lock_view)
         terrain_pass.Render(self.view, self.view, self.targets, rp)
 
+    def PrepareTerrain(self, terrain_pass, light, camera_view, max_height=400.0):
+        """vr_terrain_prepare for the shadow pass of an upcoming frame: the light view that frame's
+        SetupForPlanarViewStable(light, camera_view) will produce, built ahead on a geometry stream."""
+        lv = View()
+        check(self.ctx.lib.vr_shadow_view_setup(C.byref(light), C.byref(camera_view), C.byref(self.params), C.byref(lv)),
+              "vr_shadow_view_setup")
+        terrain_pass.Prepare(lv, self.targets, default_render_params(max_height, depth_only=1, assume_cleared=1))
+
     def download_depth(self):
         return self.targets.download("depth")
 
