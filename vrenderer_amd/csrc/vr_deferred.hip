@@ -40,6 +40,12 @@ struct DeferredArgs {
 // (D, G, sphere normalisation) into one reciprocal.  ~5 transcendental-rate
 // instructions per pixel and light instead of ~15 IEEE divisions.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// min / max / saturate as single instructions (v_max_f32, v_min_f32, v_med3_f32).  The generic a > b ? a : b forms of
+// vr_internal.h keep C's NaN behaviour and cost a compare + select each; nothing on these paths is NaN (the only
+// non-finite inputs a G-buffer can carry, emissive halves, are added at the very end).
+__device__ __forceinline__ float fmax1(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float fmin1(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float fsat1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float dot3c(float ax, float ay, float az, float bx, float by, float bz)
 {
@@ -64,9 +70,9 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
     for (int c = 0; c < 3; c++) { s.albedo[c] = lut[(diff >> (8 * c)) & 255u]; s.F0[c] = lut[(spec >> (8 * c)) & 255u]; }
     s.occlusion = (float)(spec >> 24) * (1.0f / 255.0f);
     const float sn16 = 1.0f / 32767.0f;
-    s.N[0] = vr_max((float)(int16_t)(n01 & 0xffffu) * sn16, -1.0f); s.N[1] = vr_max((float)(int16_t)(n01 >> 16) * sn16, -1.0f);
-    s.N[2] = vr_max((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f);
-    const float rough = vr_max((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
+    s.N[0] = fmax1((float)(int16_t)(n01 & 0xffffu) * sn16, -1.0f); s.N[1] = fmax1((float)(int16_t)(n01 >> 16) * sn16, -1.0f);
+    s.N[2] = fmax1((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f);
+    const float rough = fmax1((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
     s.E[0] = vr_half_to_float(e01 & 0xffffu); s.E[1] = vr_half_to_float(e01 >> 16); s.E[2] = vr_half_to_float(e23 & 0xffffu);
     if (known_wp) { s.wp[0] = known_wp[0]; s.wp[1] = known_wp[1]; s.wp[2] = known_wp[2]; }
     else {
@@ -100,8 +106,8 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
     const float two = 2.0f * NdotVi;
 #pragma unroll
     for (int c = 0; c < 3; c++) s.R[c] = s.vi[c] - s.N[c] * two;        // reflect(viewIncident, N)
-    const float NdotV = vr_saturate(-NdotVi);
-    s.alpha = vr_max(0.01f, rough * rough);
+    const float NdotV = fsat1(-NdotVi);
+    s.alpha = fmax1(0.01f, rough * rough);
     s.a2 = s.alpha * s.alpha;
     s.kk = ((rough + 1.0f) * (rough + 1.0f)) * 0.125f;
     s.gv = NdotV * (1.0f - s.kk) + s.kk;
@@ -130,21 +136,21 @@ __device__ __forceinline__ void add_light(const Surface& s, int type, const floa
         float att = 1.0f;
         if (inv_range > 0.0f) {
             const float q2 = d2 * (inv_range * inv_range);
-            const float sa = vr_saturate(1.0f - q2 * q2);
+            const float sa = fsat1(1.0f - q2 * q2);
             att = sa * sa;
             if (att == 0.0f) return;
         }
         irr = intensity * (rd * rd);
         if (extra != nullptr) {
             if (type == VR_LIGHT_SPOT) {
-                const float LdotD = vr_min(vr_max(-dot3c(L[0], L[1], L[2], extra->axis[0], extra->axis[1], extra->axis[2]), -1.0f), 1.0f);
-                const float ts = vr_saturate((acosf(LdotD) - extra->inner_angle) * fast_rcp(extra->outer_angle - extra->inner_angle));
+                const float LdotD = fmin1(fmax1(-dot3c(L[0], L[1], L[2], extra->axis[0], extra->axis[1], extra->axis[2]), -1.0f), 1.0f);
+                const float ts = fsat1((acosf(LdotD) - extra->inner_angle) * fast_rcp(extra->outer_angle - extra->inner_angle));
                 const float spotlight = 1.0f - ts * ts * (3.0f - 2.0f * ts);
                 if (spotlight == 0.0f) return;
                 att *= spotlight;
             }
             if (extra->radius > 0.0f) {
-                const float x = vr_min(extra->radius * rd, 1.0f);
+                const float x = fmin1(extra->radius * rd, 1.0f);
                 const float halfAng = atanf(x);
                 irr = (intensity * fast_rcp(extra->radius * extra->radius)) * (halfAng * halfAng);
                 tanH = x; cosH = fast_rsq(1.0f + x * x); sinH = x * cosH;
@@ -152,23 +158,23 @@ __device__ __forceinline__ void add_light(const Surface& s, int type, const floa
         }
         irr *= att;
     }
-    const float NdotLd = vr_max(dot3c(s.N[0], s.N[1], s.N[2], L[0], L[1], L[2]), 0.0f);
+    const float NdotLd = fmax1(dot3c(s.N[0], s.N[1], s.N[2], L[0], L[1], L[2]), 0.0f);
     const float kd = (NdotLd * VR_INV_PI) * irr;
     // area-light correction of L towards R (closed form of Donut's slerp)
-    const float cosT = vr_min(vr_max(dot3c(s.R[0], s.R[1], s.R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
+    const float cosT = fmin1(fmax1(dot3c(s.R[0], s.R[1], s.R[2], L[0], L[1], L[2]), -1.0f), 1.0f);
     float k1 = 0.0f, k2 = 1.0f;                                       // cosT >= cosH: CL = R
     if (cosT < cosH) {
-        k2 = sinH * fast_rsq(vr_max(1.0f - cosT * cosT, 1e-12f));
+        k2 = sinH * fast_rsq(fmax1(1.0f - cosT * cosT, 1e-12f));
         k1 = cosH - cosT * k2;
     }
     const float CL[3] = { L[0] * k1 + s.R[0] * k2, L[1] * k1 + s.R[1] * k2, L[2] * k1 + s.R[2] * k2 };
     const float Hv[3] = { CL[0] - s.vi[0], CL[1] - s.vi[1], CL[2] - s.vi[2] };
     const float hl2 = dot3c(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
     const float hs = hl2 > 0.0f ? fast_rsq(hl2) : 0.0f;
-    const float NdotH = vr_saturate(dot3c(s.N[0], s.N[1], s.N[2], Hv[0], Hv[1], Hv[2]) * hs);
-    const float NdotL = vr_saturate(dot3c(s.N[0], s.N[1], s.N[2], CL[0], CL[1], CL[2]));
-    const float VdotH = vr_saturate(-dot3c(s.vi[0], s.vi[1], s.vi[2], Hv[0], Hv[1], Hv[2]) * hs);
-    const float corrAlpha = vr_saturate(s.alpha + 0.5f * tanH);
+    const float NdotH = fsat1(dot3c(s.N[0], s.N[1], s.N[2], Hv[0], Hv[1], Hv[2]) * hs);
+    const float NdotL = fsat1(dot3c(s.N[0], s.N[1], s.N[2], CL[0], CL[1], CL[2]));
+    const float VdotH = fsat1(-dot3c(s.vi[0], s.vi[1], s.vi[2], Hv[0], Hv[1], Hv[2]) * hs);
+    const float corrAlpha = fsat1(s.alpha + 0.5f * tanH);
     const float dd = (NdotH * NdotH) * (s.a2 - 1.0f) + 1.0f;
     const float gl = NdotL * (1.0f - s.kk) + s.kk;
     // D * G * NdotL / 4 * irradiance with D = a2/(pi dd^2) (alpha/corrAlpha)^2, G = 1/(gl gv)
@@ -309,8 +315,11 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
 // PACKED = false: whole frame, row-major output; one lane = 4 consecutive pixels.
 // PACKED = true : only owner tiles of this rank, output packed tile-major
 //                 [local tile][128 rows][128 px]; block = 8 rows x 128 px of a tile.
+#ifndef VR_DEFERRED_WAVES
+#define VR_DEFERRED_WAVES 4
+#endif
 template <bool PACKED, bool EXTRA, bool SHADOW = false>
-__global__ __launch_bounds__(256) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
+__global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                    const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
                                                    uint2* __restrict__ out, const float* __restrict__ lut_g,
@@ -524,16 +533,16 @@ __global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const 
             const float4 d = *reinterpret_cast<const float4*>(g_depth + (size_t)py * a.w + px);
             const float v[4] = { d.x, d.y, d.z, d.w };
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = vr_min(dmin, v[k]); dmax = vr_max(dmax, v[k]); }
+            for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = fmin1(dmin, v[k]); dmax = fmax1(dmax, v[k]); }
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { dmin = vr_min(dmin, __shfl_xor(dmin, off)); dmax = vr_max(dmax, __shfl_xor(dmax, off)); }
+    for (int off = 32; off >= 1; off >>= 1) { dmin = fmin1(dmin, __shfl_xor(dmin, off)); dmax = fmax1(dmax, __shfl_xor(dmax, off)); }
     if (lane == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
     if (tid == 0) s_count = 0u;
     __syncthreads();
-    dmin = vr_min(vr_min(s_min[0], s_min[1]), vr_min(s_min[2], s_min[3]));
-    dmax = vr_max(vr_max(s_max[0], s_max[1]), vr_max(s_max[2], s_max[3]));
+    dmin = fmin1(fmin1(s_min[0], s_min[1]), fmin1(s_min[2], s_min[3]));
+    dmax = fmax1(fmax1(s_max[0], s_max[1]), fmax1(s_max[2], s_max[3]));
     if (!(dmin <= dmax)) { if (tid == 0) list[0] = 0u; return; }    // nothing covered: every tile inside skips its lights
     if (wave == 0) {
         // the cell's 8 corners (window edges of the tile x {dmin, dmax}), reconstructed in the shading pass's exact order
@@ -552,8 +561,8 @@ __global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const 
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], __shfl_xor(lo[c], off)); hi[c] = vr_max(hi[c], __shfl_xor(hi[c], off)); }
-            far2 = vr_max(far2, __shfl_xor(far2, off));
+            for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmax1(hi[c], __shfl_xor(hi[c], off)); }
+            far2 = fmax1(far2, __shfl_xor(far2, off));
         }
         // Far from the camera clip -> world loses bits (w cancels): a pixel's reconstructed position and these corners may
         // each be off by ~1.5e-3 of their distance (2.4 units at 1600).  The pad covers both.
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const 
             else {
                 float d2 = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 3; c++) { const float d = vr_max(vr_max(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
+                for (int c = 0; c < 3; c++) { const float d = fmax1(fmax1(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
                 const float r = 1.0f / L.inv_range;
                 keep = d2 <= (r * r) * 1.0001f;
             }
@@ -669,24 +678,24 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
             pos[0] = w4[0] * rw; pos[1] = w4[1] * rw; pos[2] = w4[2] * rw;
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], pos[c]); hi[c] = vr_max(hi[c], pos[c]); }
+        for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], pos[c]); hi[c] = fmax1(hi[c], pos[c]); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) { lo[c] = vr_min(lo[c], __shfl_xor(lo[c], off)); hi[c] = vr_max(hi[c], __shfl_xor(hi[c], off)); }
+        for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmax1(hi[c], __shfl_xor(hi[c], off)); }
     }
     if (lane == 0) { for (int c = 0; c < 3; c++) { s_box[wave][c] = lo[c]; s_box[wave][3 + c] = hi[c]; } }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        lo[c] = vr_min(vr_min(s_box[0][c], s_box[1][c]), vr_min(s_box[2][c], s_box[3][c]));
-        hi[c] = vr_max(vr_max(s_box[0][3 + c], s_box[1][3 + c]), vr_max(s_box[2][3 + c], s_box[3][3 + c]));
+        lo[c] = fmin1(fmin1(s_box[0][c], s_box[1][c]), fmin1(s_box[2][c], s_box[3][c]));
+        hi[c] = fmax1(fmax1(s_box[0][3 + c], s_box[1][3 + c]), fmax1(s_box[2][3 + c], s_box[3][3 + c]));
     }
     const bool any_covered = lo[0] <= hi[0];
     // reconstruction here and in decode_surface may differ in the last bit: pad the box
 #pragma unroll
-    for (int c = 0; c < 3; c++) { const float pad = 1e-4f * vr_max(fabsf(lo[c]), fabsf(hi[c])) + 1e-6f; lo[c] -= pad; hi[c] += pad; }
+    for (int c = 0; c < 3; c++) { const float pad = 1e-4f * fmax1(fabsf(lo[c]), fabsf(hi[c])) + 1e-6f; lo[c] -= pad; hi[c] += pad; }
 
     // ---- 2. cull the macro tile's list (k_light_macro_cull), 256 lights per round, list kept in light order
     const uint32_t* __restrict__ mlist = macro_lists + (size_t)((py / kMacroTile) * macro_x + (px0 / kMacroTile)) * macro_stride;
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
             else {
                 float d2 = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 3; c++) { const float d = vr_max(vr_max(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
+                for (int c = 0; c < 3; c++) { const float d = fmax1(fmax1(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
                 const float r = 1.0f / L.inv_range;
                 keep = d2 <= (r * r) * 1.0001f;                      // attenuation is exactly 0 from the range outwards
             }
