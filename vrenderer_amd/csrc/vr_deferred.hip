@@ -59,10 +59,8 @@ struct Surface {
     float occlusion, alpha, a2, kk, gv;
 };
 
-// known_wp: the world position, when the caller has already reconstructed it (the tiled pass's tile box)
 __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const float* __restrict__ lut, int px, int py, float depth,
-                                                  uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23,
-                                                  const float* known_wp = nullptr)
+                                                  uint32_t diff, uint32_t spec, uint32_t n01, uint32_t n23, uint32_t e01, uint32_t e23)
 {
 #pragma clang fp contract(fast)
     Surface s;
@@ -74,29 +72,32 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
     s.N[2] = fmax1((float)(int16_t)(n23 & 0xffffu) * sn16, -1.0f);
     const float rough = fmax1((float)(int16_t)(n23 >> 16) * sn16, -1.0f);
     s.E[0] = vr_half_to_float(e01 & 0xffffu); s.E[1] = vr_half_to_float(e01 >> 16); s.E[2] = vr_half_to_float(e23 & 0xffffu);
-    if (known_wp) { s.wp[0] = known_wp[0]; s.wp[1] = known_wp[1]; s.wp[2] = known_wp[2]; }
-    else {
+    {
         // ReconstructWorldPosition: window -> clip -> world
         float cx, cy;
         {
     #pragma clang fp contract(off)
             cx = ((float)px + 0.5f) * a.sx + -1.0f; cy = ((float)py + 0.5f) * a.sy + 1.0f;
         }
-        float wp4[4];
-    #pragma unroll
-        for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
-        const float rw = fast_rcp(wp4[3]);
-        s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
         if (a.exact_pos) {
             // Far from the camera clip -> world is ill-conditioned (w = depth * c2w[11] + c2w[15] cancels to a few significant
             // bits: at depth 0.9999 one rounding moves the point by a world unit).  A directional light does not care, a
-            // point light's distance and direction do, so with positional lights in the list the position is evaluated in the
-            // checker's exact order - no contraction, IEEE divisions (wave-uniform branch; the sun-only pass is unchanged).
+            // point light's distance and direction do, so with positional lights in the list the sums are evaluated in the
+            // checker's order, without contraction (wave-uniform branch; the sun-only pass is unchanged).  One correctly
+            // rounded 1/w and three products instead of the checker's three divisions: a last-place difference of the
+            // quotients is not amplified, the cancellation is in the sums.
     #pragma clang fp contract(off)
             float e4[4];
     #pragma unroll
             for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
-            s.wp[0] = e4[0] / e4[3]; s.wp[1] = e4[1] / e4[3]; s.wp[2] = e4[2] / e4[3];
+            const float rw4 = 1.0f / e4[3];
+            s.wp[0] = e4[0] * rw4; s.wp[1] = e4[1] * rw4; s.wp[2] = e4[2] * rw4;
+        } else {
+            float wp4[4];
+    #pragma unroll
+            for (int j = 0; j < 4; j++) wp4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
+            const float rw = fast_rcp(wp4[3]);
+            s.wp[0] = wp4[0] * rw; s.wp[1] = wp4[1] * rw; s.wp[2] = wp4[2] * rw;
         }
     }
     const float d[3] = { s.wp[0] - a.cam[0], s.wp[1] - a.cam[1], s.wp[2] - a.cam[2] };
@@ -121,7 +122,7 @@ struct LightExtra { float axis[3]; float radius, inner_angle, outer_angle; };
 
 __device__ __forceinline__ void add_light(const Surface& s, int type, const float vec[3], float inv_range, const float color[3],
                                           float intensity, float cosH, float sinH, float tanH, float diffuseTerm[3], float specularTerm[3],
-                                          const LightExtra* extra = nullptr)
+                                          const LightExtra* extra = nullptr, bool punctual = false)
 {
 #pragma clang fp contract(fast)
     float L[3], irr;                                                  // L = -incidentVector
@@ -167,7 +168,10 @@ __device__ __forceinline__ void add_light(const Surface& s, int type, const floa
         k2 = sinH * fast_rsq(fmax1(1.0f - cosT * cosT, 1e-12f));
         k1 = cosH - cosT * k2;
     }
-    const float CL[3] = { L[0] * k1 + s.R[0] * k2, L[1] * k1 + s.R[1] * k2, L[2] * k1 + s.R[2] * k2 };
+    // punctual (compile-time; the tiled pass's point lights, cosH = 1, sinH = 0): k1 = 1, k2 = 0 and CL = L, except where
+    // R.L rounds to 1 or more - there the general form takes R, which then equals L to within rounding
+    const float CL[3] = { punctual ? L[0] : L[0] * k1 + s.R[0] * k2, punctual ? L[1] : L[1] * k1 + s.R[1] * k2,
+                          punctual ? L[2] : L[2] * k1 + s.R[2] * k2 };
     const float Hv[3] = { CL[0] - s.vi[0], CL[1] - s.vi[1], CL[2] - s.vi[2] };
     const float hl2 = dot3c(Hv[0], Hv[1], Hv[2], Hv[0], Hv[1], Hv[2]);
     const float hs = hl2 > 0.0f ? fast_rsq(hl2) : 0.0f;
@@ -491,66 +495,97 @@ extern "C" VR_API int vr_deferred_light_shadowed(vr_context* ctx, const vr_view*
 }
 
 // ---- tiled deferred lighting for many point lights (BASELINE config 5) ---------------------------
-// One workgroup = one 32x32 pixel tile, one lane = 4 horizontally adjacent pixels (16-byte loads and
-// stores, as in k_deferred).  Phases:
-//   1. load the lane's 4 pixels, reconstruct their world positions and reduce the world-space
-//      bounding box of the tile's covered pixels (wave shuffles, then 4 partial boxes through LDS);
-//   2. cull: lane t tests light c*256+t (sphere = position/range vs the tile box; directional lights
-//      always pass); survivors are appended to an LDS list in light order with a wave ballot + popcount
-//      prefix, and their constants are staged in LDS (48 B each);
-//   3. shade: the lane walks the tile's list once per pixel (LDS broadcast reads) with the same BRDF
-//      as k_deferred.
-// A light culled here has zero attenuation for every pixel of the tile, so the sum equals the
-// all-lights loop of the oracle.
+// Two kernels.
+//   k_light_cull: one workgroup per 128x128 macro tile (= owner tile).  Depth range of the macro tile and of each of its
+//      sixteen 32x32 light tiles -> the world-space boxes of those frustum cells (8 corners each) -> every light is tested
+//      against the macro box and, if it touches it, against the sixteen small ones; survivors are appended to the light
+//      tiles' lists in global memory (count, then indices, in light order: ballot + popcount prefix).
+//   k_deferred_tiled: one workgroup = one 32x32 light tile, one lane = 4 horizontally adjacent pixels (16-byte loads
+//      and stores, as in k_deferred).  The tile's lights are staged through LDS 256 at a time (32 B each, one fetch
+//      latency for the whole list), then every lane walks them (LDS broadcast reads) with the same BRDF as k_deferred.
+// A light culled here has zero attenuation for every pixel of the tile, so the sum equals the all-lights loop of the
+// oracle.  (Round 2's first version culled inside the shading kernel - per-pixel position boxes, five barriers and a
+// 32-KB list per workgroup; its fixed cost was 150 us per 8K frame over k_deferred's.)
 constexpr int kLightTile = 32;
 constexpr int kTileLightCap = VR_TILE_LIGHT_CAP;
-// 32 B per staged light (4 workgroups of 1024 lights fit a CU's LDS): colour premultiplied by the intensity;
-// w = 0 for a point light, 1 + half angular size for a directional one (its cos/sin/tan are then taken per pixel).
+constexpr int kStageLights = 256;
+// 32 B per staged light: colour premultiplied by the intensity; w = 0 for a point light; for a directional one
+// w = cos and inv_range = sin of its angular half size.
 struct TiledLight { float vec[3]; float inv_range; float color[3]; float w; };
 
-// Coarse culling, one workgroup per 128x128 macro tile (= owner tile): depth range of the tile's covered pixels -> the
-// world-space box of that frustum cell (its 8 corners) -> the lights whose sphere touches the box, in light order, as a
-// global list (count, then indices).  The 32x32 tiles of k_deferred_tiled then test a few dozen lights each instead of
-// all of them (1024 lights x 32,400 tiles x 64 B per light was most of that kernel's time at 8K).
 constexpr int kMacroTile = VR_OWNER_TILE;
-__global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
-                                                           const float* __restrict__ g_depth, int macro_x,
-                                                           const int32_t* __restrict__ owned_tiles, uint32_t* __restrict__ lists, int stride)
+constexpr int kSubSide = kMacroTile / kLightTile;       // 4 light tiles per macro tile side
+constexpr int kSubTiles = kSubSide * kSubSide;
+static_assert(kSubTiles == 16 && kMacroTile == 128, "k_light_cull's lane mapping assumes 128-px macro tiles of 4x4 light tiles");
+
+// squared distance from a point to a box, compared with the light's range (attenuation is exactly 0 from the range outwards)
+__device__ __forceinline__ bool sphere_touches(const float* __restrict__ box, const float pos[3], float r2)
 {
-    __shared__ float s_min[4], s_max[4];
-    __shared__ float s_box[6];
-    __shared__ uint32_t s_wave_count[4];
-    __shared__ uint32_t s_count;
+    float d2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float d = fmax1(fmax1(box[c] - pos[c], pos[c] - box[3 + c]), 0.0f); d2 += d * d; }
+    return d2 <= r2;
+}
+
+__global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
+                                                     const float* __restrict__ g_depth, int macro_x,
+                                                     const int32_t* __restrict__ owned_tiles, uint32_t* __restrict__ lists, int stride,
+                                                     int tiles32_x, int tiles32_y, uint32_t* __restrict__ overflow_flag)
+{
+    __shared__ uint32_t s_dmin[kSubTiles], s_dmax[kSubTiles];   // bits of non-negative floats: ordered like the floats
+    __shared__ float s_box[kSubTiles + 1][6];                   // the light tiles' boxes, then the macro tile's
+    __shared__ uint32_t s_wave_count[4][kSubTiles];
+    __shared__ uint32_t s_count[kSubTiles];
+    __shared__ uint32_t s_covered;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = owned_tiles ? owned_tiles[blockIdx.x] : (int)blockIdx.x;
     const int ty = tile / macro_x, tx = tile - ty * macro_x;
     const int x0 = tx * kMacroTile, y0 = ty * kMacroTile;
-    uint32_t* __restrict__ list = lists + (size_t)tile * stride;
-    float dmin = 2.0f, dmax = -1.0f;
-    for (int r = 0; r < kMacroTile / 8; r++) {
-        const int py = y0 + r * 8 + (tid >> 5), px = x0 + (tid & 31) * 4;
-        if (py < a.h && px < a.w) {                                 // the frame width is a multiple of 4
-            const float4 d = *reinterpret_cast<const float4*>(g_depth + (size_t)py * a.w + px);
-            const float v[4] = { d.x, d.y, d.z, d.w };
+    if (tid < kSubTiles) { s_dmin[tid] = 0x7f800000u; s_dmax[tid] = 0u; s_count[tid] = 0u; }
+    if (tid == 0) s_covered = 0u;
+    __syncthreads();
+    // ---- depth range per light tile: lane = 4 px of a row; a wave holds two rows of the macro tile per step
+    const int sub_x = (tid & 31) >> 3;
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = fmin1(dmin, v[k]); dmax = fmax1(dmax, v[k]); }
+    for (int sub_y = 0; sub_y < kSubSide; sub_y++) {
+        float dmin = 2.0f, dmax = -1.0f;
+#pragma unroll
+        for (int r = sub_y * 4; r < sub_y * 4 + 4; r++) {
+            const int py = y0 + r * 8 + (tid >> 5), px = x0 + (tid & 31) * 4;
+            if (py < a.h && px < a.w) {                                 // the frame width is a multiple of 4
+                const float4 d = *reinterpret_cast<const float4*>(g_depth + (size_t)py * a.w + px);
+                const float v[4] = { d.x, d.y, d.z, d.w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = fmin1(dmin, v[k]); dmax = fmax1(dmax, v[k]); }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) { dmin = fmin1(dmin, __shfl_xor(dmin, off)); dmax = fmax1(dmax, __shfl_xor(dmax, off)); }
+        dmin = fmin1(dmin, __shfl_xor(dmin, 32)); dmax = fmax1(dmax, __shfl_xor(dmax, 32));
+        if ((lane & 39) == 0 && dmin <= dmax) {                          // lanes 0, 8, 16, 24: one per light-tile column
+            atomicMin(&s_dmin[sub_y * kSubSide + sub_x], __float_as_uint(dmin) & 0x7fffffffu);
+            atomicMax(&s_dmax[sub_y * kSubSide + sub_x], __float_as_uint(dmax) & 0x7fffffffu);
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { dmin = fmin1(dmin, __shfl_xor(dmin, off)); dmax = fmax1(dmax, __shfl_xor(dmax, off)); }
-    if (lane == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
-    if (tid == 0) s_count = 0u;
     __syncthreads();
-    dmin = fmin1(fmin1(s_min[0], s_min[1]), fmin1(s_min[2], s_min[3]));
-    dmax = fmax1(fmax1(s_max[0], s_max[1]), fmax1(s_max[2], s_max[3]));
-    if (!(dmin <= dmax)) { if (tid == 0) list[0] = 0u; return; }    // nothing covered: every tile inside skips its lights
-    if (wave == 0) {
-        // the cell's 8 corners (window edges of the tile x {dmin, dmax}), reconstructed in the shading pass's exact order
-        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f }, far2 = 0.0f;
-        if (lane < 8) {
+    // ---- boxes: 8 lanes per cell (its corners: window edges x {dmin, dmax}), reconstructed in the shading pass's exact order
+    if (tid < (kSubTiles + 1) * 8) {
+        const int b = tid >> 3, corner = tid & 7;
+        uint32_t bmin, bmax; int cx0, cy0, cx1, cy1;
+        if (b < kSubTiles) {
+            bmin = s_dmin[b]; bmax = s_dmax[b];
+            cx0 = x0 + (b & 3) * kLightTile; cy0 = y0 + (b >> 2) * kLightTile; cx1 = cx0 + kLightTile; cy1 = cy0 + kLightTile;
+        } else {
+            bmin = 0x7f800000u; bmax = 0u;
+            for (int i = 0; i < kSubTiles; i++) { bmin = min(bmin, s_dmin[i]); bmax = max(bmax, s_dmax[i]); }
+            cx0 = x0; cy0 = y0; cx1 = x0 + kMacroTile; cy1 = y0 + kMacroTile;
+        }
+        const bool covered = bmin <= bmax;
+        float lo[3], hi[3], far2 = 0.0f;
+        {
 #pragma clang fp contract(off)
-            const float wx = (float)(lane & 1 ? min(x0 + kMacroTile, a.w) : x0), wy = (float)(lane & 2 ? min(y0 + kMacroTile, a.h) : y0);
-            const float depth = lane & 4 ? dmax : dmin;
+            const float wx = (float)(corner & 1 ? min(cx1, a.w) : cx0), wy = (float)(corner & 2 ? min(cy1, a.h) : cy0);
+            const float depth = __uint_as_float(corner & 4 ? bmax : bmin);
             const float cx = wx * a.sx + -1.0f, cy = wy * a.sy + 1.0f;
             float e4[4];
 #pragma unroll
@@ -567,75 +602,104 @@ __global__ __launch_bounds__(256) void k_light_macro_cull(DeferredArgs a, const 
         // Far from the camera clip -> world loses bits (w cancels): a pixel's reconstructed position and these corners may
         // each be off by ~1.5e-3 of their distance (2.4 units at 1600).  The pad covers both.
         const float pad = 4.0e-3f * sqrtf(far2) + 1.0e-2f;
-        if (lane == 0) { for (int c = 0; c < 3; c++) { s_box[c] = lo[c] - pad; s_box[3 + c] = hi[c] + pad; } }
+        if (corner == 0) {
+            // nothing covered: an empty box (no light touches it; the tile's pixels are background and receive none)
+            for (int c = 0; c < 3; c++) { s_box[b][c] = covered ? lo[c] - pad : 3.0e38f; s_box[b][3 + c] = covered ? hi[c] + pad : -3.0e38f; }
+            if (covered && b < kSubTiles) atomicOr(&s_covered, 1u << b);
+        }
     }
     __syncthreads();
-    const float lo[3] = { s_box[0], s_box[1], s_box[2] }, hi[3] = { s_box[3], s_box[4], s_box[5] };
-    for (int base = 0; base < num_lights; base += 256) {
-        const int li = base + tid;
-        bool keep = false;
-        if (li < num_lights) {
-            const DevLight L = lights[li];
-            if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) keep = true;
-            else {
-                float d2 = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 3; c++) { const float d = fmax1(fmax1(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
-                const float r = 1.0f / L.inv_range;
-                keep = d2 <= (r * r) * 1.0001f;
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = s_count;
-        for (int w = 0; w < wave; w++) before += s_wave_count[w];
-        const uint32_t total = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-        if (keep) list[1u + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)li;
-        __syncthreads();
-        if (tid == 0) s_count += total;
-        __syncthreads();
+    const uint32_t covered_mask = s_covered;
+    const uint32_t cap = (uint32_t)(stride - 1);
+    uint32_t* __restrict__ my_list = nullptr;                         // lanes 0..15 of every wave: light tile `lane`'s list
+    if (lane < kSubTiles) {
+        const int gx = tx * kSubSide + (lane & 3), gy = ty * kSubSide + (lane >> 2);
+        if (gx < tiles32_x && gy < tiles32_y) my_list = lists + (size_t)(gy * tiles32_x + gx) * stride;
     }
-    if (tid == 0) list[0] = s_count;
+    if (covered_mask != 0u) {
+        for (int base = 0; base < num_lights; base += 256) {
+            const int li = base + tid;
+            uint32_t mask = 0u;
+            if (li < num_lights) {
+                const DevLight L = lights[li];
+                if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) mask = covered_mask;
+                else {
+                    const float r = 1.0f / L.inv_range, r2 = (r * r) * 1.0001f;
+                    if (sphere_touches(s_box[kSubTiles], L.pos, r2)) {
+#pragma unroll
+                        for (int b = 0; b < kSubTiles; b++) mask |= sphere_touches(s_box[b], L.pos, r2) ? 1u << b : 0u;
+                    }
+                }
+            }
+            // ordered append: per light tile, this wave's survivors, then the offsets of the waves before it
+            uint32_t mine = 0u;
+#pragma unroll
+            for (int b = 0; b < kSubTiles; b++) {
+                const uint32_t c = (uint32_t)__popcll(__ballot((mask >> b) & 1u));
+                if (lane == b) mine = c;
+            }
+            if (lane < kSubTiles) s_wave_count[wave][lane] = mine;
+            __syncthreads();
+            if (__any(mask != 0u)) {
+#pragma unroll
+                for (int b = 0; b < kSubTiles; b++) {
+                    const unsigned long long m = __ballot((mask >> b) & 1u);
+                    if (m == 0ull) continue;
+                    uint32_t before = s_count[b];
+                    for (int w = 0; w < wave; w++) before += s_wave_count[w][b];
+                    uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(
+                        (uintptr_t)__shfl((unsigned long long)(uintptr_t)my_list, b));
+                    if ((mask >> b) & 1u) {
+                        const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < cap) list[1u + slot] = (uint32_t)li;
+                        else atomicOr(overflow_flag, 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < kSubTiles) s_count[tid] += s_wave_count[0][tid] + s_wave_count[1][tid] + s_wave_count[2][tid] + s_wave_count[3][tid];
+            __syncthreads();
+        }
+    }
+    if (wave == 0 && my_list) my_list[0] = min(s_count[lane], cap);
 }
 
-template <bool PACKED>
-__global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
+#ifndef VR_TILED_PXB
+#define VR_TILED_PXB 1
+#endif
+template <bool PACKED, int PXB>
+__global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights,
                                                          const float* __restrict__ g_depth, const uint32_t* __restrict__ g_diff,
                                                          const uint32_t* __restrict__ g_spec, const uint2* __restrict__ g_nrm,
                                                          const uint2* __restrict__ g_emi, uint2* __restrict__ out,
                                                          const float* __restrict__ lut_g, const int32_t* __restrict__ owned_tiles,
-                                                         uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ macro_lists,
-                                                         int macro_x, int macro_stride)
+                                                         const uint32_t* __restrict__ lists, int stride, int tiles32_x)
 {
 #pragma clang fp contract(fast)
     __shared__ float lut[256];
-    __shared__ TiledLight s_light[kTileLightCap];
-    __shared__ float s_box[4][6];
-    __shared__ uint32_t s_wave_count[4];
-    __shared__ uint32_t s_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ TiledLight s_light[kStageLights];
+    const int tid = threadIdx.x;
     lut[tid] = lut_g[tid];
-    if (tid == 0) s_count = 0u;
 
-    int px0, py; size_t out_index;
+    int px0, py, gx, gy; size_t out_index;
     const int lx = (tid & 7) * 4, ly = tid >> 3;                     // 8 lanes x 4 px per row, 32 rows
     if (PACKED) {
-        const int sub = VR_OWNER_TILE / kLightTile;                  // 4 light tiles per owner-tile side
-        const int lt = blockIdx.x / (sub * sub), st = blockIdx.x - lt * (sub * sub);
+        const int lt = blockIdx.x / kSubTiles, st = blockIdx.x - lt * kSubTiles;
         const int tile = owned_tiles[lt];
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int ox = (st % sub) * kLightTile + lx, oy = (st / sub) * kLightTile + ly;
-        px0 = tx * VR_OWNER_TILE + ox; py = ty * VR_OWNER_TILE + oy;
+        gx = tx * kSubSide + (st & 3); gy = ty * kSubSide + (st >> 2);
+        const int ox = (st & 3) * kLightTile + lx, oy = (st >> 2) * kLightTile + ly;
         out_index = ((size_t)lt * VR_OWNER_TILE + oy) * VR_OWNER_TILE + ox;
     } else {
-        const int tiles_x = (a.w + kLightTile - 1) / kLightTile;
-        const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-        px0 = tx * kLightTile + lx; py = ty * kLightTile + ly;
-        out_index = (size_t)py * a.w + px0;
+        gy = blockIdx.x / tiles32_x; gx = blockIdx.x - gy * tiles32_x;
+        out_index = (size_t)(gy * kLightTile + ly) * a.w + (gx * kLightTile + lx);
     }
+    px0 = gx * kLightTile + lx; py = gy * kLightTile + ly;
     const bool inside = px0 < a.w && py < a.h;                       // the frame width is a multiple of 4
-    __syncthreads();
+    // (a packed owner tile may hang over the frame's edge: light tiles outside it have no list)
+    const bool listed = gx < tiles32_x && gy * kLightTile < a.h;
+    const uint32_t* __restrict__ list = lists + (size_t)(gy * tiles32_x + gx) * stride;
+    const uint32_t n = listed ? list[0] : 0u;
 
     float depth[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
     uint32_t dfa[4] = { 0, 0, 0, 0 }, spa[4] = { 0, 0, 0, 0 }, na[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ea[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -653,116 +717,63 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
         na[0] = n0.x; na[1] = n0.y; na[2] = n0.z; na[3] = n0.w; na[4] = n1.x; na[5] = n1.y; na[6] = n1.z; na[7] = n1.w;
         ea[0] = e0.x; ea[1] = e0.y; ea[2] = e0.z; ea[3] = e0.w; ea[4] = e1.x; ea[5] = e1.y; ea[6] = e1.z; ea[7] = e1.w;
     }
-    // ---- 1. tile bounding box in world space (background pixels receive no light: albedo = F0 = N = 0)
-    const float big = 3.0e38f;
-    float lo[3] = { big, big, big }, hi[3] = { -big, -big, -big };
-    float wpos[4][3];                                                // the pixels' world positions, reused by the shading below
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float* pos = wpos[k];
-        pos[0] = pos[1] = pos[2] = 0.0f;
-        if (!(inside && depth[k] < 1.0f)) continue;
-        if (a.exact_pos) {       // the positions the shading below uses (decode_surface): far pixels are ill-conditioned
-#pragma clang fp contract(off)
-            const float cx = ((float)(px0 + k) + 0.5f) * a.sx + -1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
-            float e4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth[k] * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
-            pos[0] = e4[0] / e4[3]; pos[1] = e4[1] / e4[3]; pos[2] = e4[2] / e4[3];
-        } else {
-            const float cx = ((float)(px0 + k) + 0.5f) * a.sx - 1.0f, cy = ((float)py + 0.5f) * a.sy + 1.0f;
-            float w4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) w4[j] = cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j] + depth[k] * a.c2w[2 * 4 + j] + a.c2w[3 * 4 + j];
-            const float rw = fast_rcp(w4[3]);
-            pos[0] = w4[0] * rw; pos[1] = w4[1] * rw; pos[2] = w4[2] * rw;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], pos[c]); hi[c] = fmax1(hi[c], pos[c]); }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmax1(hi[c], __shfl_xor(hi[c], off)); }
-    }
-    if (lane == 0) { for (int c = 0; c < 3; c++) { s_box[wave][c] = lo[c]; s_box[wave][3 + c] = hi[c]; } }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        lo[c] = fmin1(fmin1(s_box[0][c], s_box[1][c]), fmin1(s_box[2][c], s_box[3][c]));
-        hi[c] = fmax1(fmax1(s_box[0][3 + c], s_box[1][3 + c]), fmax1(s_box[2][3 + c], s_box[3][3 + c]));
-    }
-    const bool any_covered = lo[0] <= hi[0];
-    // reconstruction here and in decode_surface may differ in the last bit: pad the box
-#pragma unroll
-    for (int c = 0; c < 3; c++) { const float pad = 1e-4f * fmax1(fabsf(lo[c]), fabsf(hi[c])) + 1e-6f; lo[c] -= pad; hi[c] += pad; }
-
-    // ---- 2. cull the macro tile's list (k_light_macro_cull), 256 lights per round, list kept in light order
-    const uint32_t* __restrict__ mlist = macro_lists + (size_t)((py / kMacroTile) * macro_x + (px0 / kMacroTile)) * macro_stride;
-    const int n_macro = any_covered ? (int)mlist[0] : 0;       // (py, px0: this lane's pixel; the whole 32x32 tile lies in one macro tile)
-    for (int base = 0; base < n_macro; base += 256) {
-        const int li = base + tid;
-        bool keep = false;
-        DevLight L;
-        if (li < n_macro) {
-            L = lights[mlist[1 + li]];
-            if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) keep = true;
-            else {
-                float d2 = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 3; c++) { const float d = fmax1(fmax1(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f); d2 += d * d; }
-                const float r = 1.0f / L.inv_range;
-                keep = d2 <= (r * r) * 1.0001f;                      // attenuation is exactly 0 from the range outwards
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = s_count;
-        for (int w = 0; w < wave; w++) before += s_wave_count[w];
-        const uint32_t total = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-        if (keep) {
-            const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < (uint32_t)kTileLightCap) {
-                TiledLight t;
-                const float* v = L.type == VR_LIGHT_DIRECTIONAL ? L.dir : L.pos;
-                t.vec[0] = v[0]; t.vec[1] = v[1]; t.vec[2] = v[2]; t.inv_range = L.inv_range;
-                t.color[0] = L.color[0] * L.intensity; t.color[1] = L.color[1] * L.intensity; t.color[2] = L.color[2] * L.intensity;
-                t.w = L.type == VR_LIGHT_DIRECTIONAL ? 1.0f + atan2f(L.sinH, L.cosH) : 0.0f;
-                s_light[slot] = t;
-            } else atomicOr(overflow_flag, 1u);
-        }
-        __syncthreads();
-        if (tid == 0) s_count = min(s_count + total, (uint32_t)kTileLightCap);
-        __syncthreads();
-    }
-
-    // ---- 3. shade
-    if (!inside) return;
-    const uint32_t n = s_count;
     uint32_t o[8];
+    // The tile's lights go through LDS 256 at a time: one round - staged once, before the pixel loop - unless the tile
+    // keeps more than that; then every pixel batch walks the rounds itself (barriers inside; n is workgroup-uniform).
+    const bool multi = n > (uint32_t)kStageLights;
+    auto stage = [&](uint32_t chunk) {
+        if (chunk + (uint32_t)tid < n) {
+            const DevLight L = lights[list[1u + chunk + tid]];
+            const bool dir = L.type == VR_LIGHT_DIRECTIONAL;
+            TiledLight t;
+            const float* v = dir ? L.dir : L.pos;
+            t.vec[0] = v[0]; t.vec[1] = v[1]; t.vec[2] = v[2]; t.inv_range = dir ? L.sinH : L.inv_range;
+            t.color[0] = L.color[0] * L.intensity; t.color[1] = L.color[1] * L.intensity; t.color[2] = L.color[2] * L.intensity;
+            t.w = dir ? L.cosH : 0.0f;
+            s_light[tid] = t;
+        }
+    };
+    if (!multi) stage(0u);
+    __syncthreads();                                                 // (also publishes the decode table)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int kb = 0; kb < 4; kb += PXB) {
         // (a background pixel's position is never used: albedo = F0 = N = 0 and it receives no light)
-        const Surface s = decode_surface(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], wpos[k]);
-        float diffuseTerm[3] = { 0.0f, 0.0f, 0.0f }, specularTerm[3] = { 0.0f, 0.0f, 0.0f };
-        if (depth[k] < 1.0f) {
-            for (uint32_t i = 0; i < n; i++) {
+        Surface sv[PXB];
+        float dT[PXB][3], sT[PXB][3];
+#pragma unroll
+        for (int j = 0; j < PXB; j++) {
+            const int k = kb + j;
+            sv[j] = decode_surface(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) dT[j][c] = sT[j][c] = 0.0f;
+        }
+        for (uint32_t chunk = 0; chunk < n; chunk += kStageLights) {
+            const uint32_t m = min(n - chunk, (uint32_t)kStageLights);
+            if (multi) { __syncthreads(); stage(chunk); __syncthreads(); }
+            for (uint32_t i = 0; i < m; i++) {
                 const TiledLight& t = s_light[i];
                 if (t.w > 0.0f) {                                  // directional (block-uniform branch)
-                    const float half = t.w - 1.0f, ch = __cosf(half), sh = __sinf(half);
-                    add_light(s, VR_LIGHT_DIRECTIONAL, t.vec, 0.0f, t.color, 1.0f, ch, sh, sh * fast_rcp(ch), diffuseTerm, specularTerm);
+                    const float tanH = t.inv_range * fast_rcp(t.w);
+#pragma unroll
+                    for (int j = 0; j < PXB; j++)
+                        if (depth[kb + j] < 1.0f) add_light(sv[j], VR_LIGHT_DIRECTIONAL, t.vec, 0.0f, t.color, 1.0f, t.w, t.inv_range, tanH, dT[j], sT[j]);
                 } else {
-                    add_light(s, VR_LIGHT_POINT, t.vec, t.inv_range, t.color, 1.0f, 1.0f, 0.0f, 0.0f, diffuseTerm, specularTerm);
+#pragma unroll
+                    for (int j = 0; j < PXB; j++)
+                        if (depth[kb + j] < 1.0f) add_light(sv[j], VR_LIGHT_POINT, t.vec, t.inv_range, t.color, 1.0f, 1.0f, 0.0f, 0.0f, dT[j], sT[j], nullptr, true);
                 }
             }
         }
-        float rgb[3];
-        finish_pixel(a, s, diffuseTerm, specularTerm, rgb);
-        o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
-        o[2 * k + 1] = vr_float_to_half(rgb[2]);
+#pragma unroll
+        for (int j = 0; j < PXB; j++) {
+            const int k = kb + j;
+            float rgb[3];
+            finish_pixel(a, sv[j], dT[j], sT[j], rgb);
+            o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
+            o[2 * k + 1] = vr_float_to_half(rgb[2]);
+        }
     }
-    store_quad<PACKED>(out, out_index, o);
+    if (inside) store_quad<PACKED>(out, out_index, o);
 }
 
 extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
@@ -793,15 +804,16 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     for (int i = 0; i < num_lights; i++) if (ctx->h_lights[i].type != VR_LIGHT_DIRECTIONAL) a.exact_pos = 1;
     const bool packed = part != nullptr;
     VR_REQUIRE(gb->w % 4 == 0, "the tiled pass needs a frame width that is a multiple of 4");
-    // coarse lists: one per 128x128 macro tile, count + up to num_lights indices
+    // light lists: one per 32x32 light tile, count + up to min(num_lights, VR_TILE_LIGHT_CAP) indices
     const int macro_x = (gb->w + kMacroTile - 1) / kMacroTile, macro_y = (gb->h + kMacroTile - 1) / kMacroTile;
-    const int stride = num_lights + 1;
-    const size_t words = (size_t)macro_x * macro_y * stride;
-    if (words > ctx->macro_list_words) {
+    const int tx = (gb->w + kLightTile - 1) / kLightTile, ty = (gb->h + kLightTile - 1) / kLightTile;
+    const int stride = (num_lights < kTileLightCap ? num_lights : kTileLightCap) + 1;
+    const size_t words = (size_t)tx * ty * stride;
+    if (words > ctx->light_list_words) {
         VR_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_macro_lists); ctx->d_macro_lists = nullptr; ctx->macro_list_words = 0;
-        VR_HIP(hipMalloc(&ctx->d_macro_lists, words * sizeof(uint32_t)));
-        ctx->macro_list_words = words;
+        (void)hipFree(ctx->d_light_lists); ctx->d_light_lists = nullptr; ctx->light_list_words = 0;
+        VR_HIP(hipMalloc(&ctx->d_light_lists, words * sizeof(uint32_t)));
+        ctx->light_list_words = words;
     }
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
     if (packed) {
@@ -810,22 +822,20 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         if (rc) return rc;
         VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
-        const int sub = VR_OWNER_TILE / kLightTile;
         if (pt->num_owned > 0) {
-            hipLaunchKernelGGL(k_light_macro_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_macro_lists, stride);
-            hipLaunchKernelGGL(k_deferred_tiled<true>, dim3((unsigned)pt->num_owned * sub * sub), dim3(256), 0, ctx->stream, a, ctx->d_lights,
-                               num_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
-                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_flags, ctx->d_macro_lists, macro_x, stride);
+            hipLaunchKernelGGL(k_light_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags);
+            hipLaunchKernelGGL((k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), 0, ctx->stream, a,
+                               ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
+                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx);
         }
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
-        const int tx = (gb->w + kLightTile - 1) / kLightTile, ty = (gb->h + kLightTile - 1) / kLightTile;
-        hipLaunchKernelGGL(k_light_macro_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_macro_lists, stride);
-        hipLaunchKernelGGL(k_deferred_tiled<false>, dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+        hipLaunchKernelGGL(k_light_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags);
+        hipLaunchKernelGGL((k_deferred_tiled<false, VR_TILED_PXB>), dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
-                           (const int32_t*)nullptr, ctx->d_flags, ctx->d_macro_lists, macro_x, stride);
+                           (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;
