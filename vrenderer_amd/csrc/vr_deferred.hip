@@ -546,18 +546,25 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
     __syncthreads();
     // ---- depth range per light tile: lane = 4 px of a row; a wave holds two rows of the macro tile per step
     const int sub_x = (tid & 31) >> 3;
+    // all 16 loads first (a row outside the frame re-reads the frame's first texels and is masked below): one memory
+    // round trip per workgroup instead of sixteen
+    float4 dv[kMacroTile / 8];
+    const int px = x0 + (tid & 31) * 4;
+#pragma unroll
+    for (int r = 0; r < kMacroTile / 8; r++) {
+        const int py = y0 + r * 8 + (tid >> 5);
+        const bool ok = py < a.h && px < a.w;                           // the frame width is a multiple of 4
+        dv[r] = *reinterpret_cast<const float4*>(g_depth + (ok ? (size_t)py * a.w + px : (size_t)0));
+        if (!ok) dv[r] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    }
 #pragma unroll
     for (int sub_y = 0; sub_y < kSubSide; sub_y++) {
         float dmin = 2.0f, dmax = -1.0f;
 #pragma unroll
         for (int r = sub_y * 4; r < sub_y * 4 + 4; r++) {
-            const int py = y0 + r * 8 + (tid >> 5), px = x0 + (tid & 31) * 4;
-            if (py < a.h && px < a.w) {                                 // the frame width is a multiple of 4
-                const float4 d = *reinterpret_cast<const float4*>(g_depth + (size_t)py * a.w + px);
-                const float v[4] = { d.x, d.y, d.z, d.w };
+            const float v[4] = { dv[r].x, dv[r].y, dv[r].z, dv[r].w };
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = fmin1(dmin, v[k]); dmax = fmax1(dmax, v[k]); }
-            }
+            for (int k = 0; k < 4; k++) if (v[k] < 1.0f) { dmin = fmin1(dmin, v[k]); dmax = fmax1(dmax, v[k]); }
         }
 #pragma unroll
         for (int off = 1; off <= 4; off <<= 1) { dmin = fmin1(dmin, __shfl_xor(dmin, off)); dmax = fmax1(dmax, __shfl_xor(dmax, off)); }
