@@ -9,7 +9,8 @@ git show $REV:include/vrterrain.h > $T/include/vrterrain.h
 cd $T/vrenderer_amd/csrc
 # per-file flags as that revision's build.py had them
 EXTRA=""; if git -C /root/repo show $REV:vrenderer_amd/build.py | grep -q "fno-slp-vectorize"; then EXTRA="-fno-slp-vectorize"; fi
-for f in *.hip; do X=""; [ "$f" = vr_raster.hip ] && X=$EXTRA; /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden $X -c $f -o $T/${f%.hip}.o & done; wait
+EXTRA_D=""; if git -C /root/repo show $REV:vrenderer_amd/build.py | grep -q '"vr_deferred.hip": \["-fno-slp-vectorize"'; then EXTRA_D="-fno-slp-vectorize"; fi
+for f in *.hip; do X=""; [ "$f" = vr_raster.hip ] && X=$EXTRA; [ "$f" = vr_deferred.hip ] && X=$EXTRA_D; /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden $X -c $f -o $T/${f%.hip}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/vrenderer_amd/lib/variants/$NAME/libvrterrain.so $T/*.o -ldl
 rm -rf $T
 echo built $NAME from $REV

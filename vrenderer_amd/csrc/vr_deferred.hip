@@ -90,7 +90,7 @@ __device__ __forceinline__ Surface decode_surface(const DeferredArgs& a, const f
             float e4[4];
     #pragma unroll
             for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
-            const float rw4 = 1.0f / e4[3];
+            const float rw4 = vr_rcp_exact(e4[3]);                    // = 1.0f / w for 2^-60 <= |w| <= 2^60 (vr_internal.h)
             s.wp[0] = e4[0] * rw4; s.wp[1] = e4[1] * rw4; s.wp[2] = e4[2] * rw4;
         } else {
             float wp4[4];
