@@ -231,6 +231,7 @@ def main():
     if tiled:
         lights += vr.synthetic_point_lights(args.lights - 1, float(size), hm, 400.0, seed=9001)
     deferred = vr.TiledDeferredLightingPass(ctx) if tiled else vr.DeferredLightingPass(ctx)
+    tiled_lights = vr.light_array(lights) if tiled else None        # the vr_light[] the C ABI takes, built once
     light_kernel = "k_deferred_tiled" if tiled else "k_deferred"
     rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
 
@@ -352,7 +353,7 @@ def main():
 
     def light(v, out_img, p):
         if tiled:
-            deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p)
+            deferred.Render(v, rt, tiled_lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p)
         else:
             deferred.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, p, shadow_map=shadow_map)
 

@@ -474,6 +474,37 @@ def test_tiled_deferred_reports_tile_overflow(scene256, oracle, gpu_ctx):
     hdr.close(); rt.close()
 
 
+def test_tiled_deferred_light_list_changes_between_calls(scene256, oracle, gpu_ctx):
+    """The pass uploads a light list only when it differs from the one the device holds: same count with other colours,
+    another count, the first list again and a prebuilt vr_light[] (light_array) each light the frame their own way."""
+    w, h = 256, 144
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    v = vr.make_view(eye, tgt, w, h)
+    rt, gb = _gpu_gbuffer_as_oracle_input(oracle, gpu_ctx, scene256["tp"], v, w, h)
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    tiled = vr.TiledDeferredLightingPass(gpu_ctx)
+    rng = np.random.default_rng(77)
+
+    def some_lights(n, tint):
+        return [vr.reference_sun()] + [vr.point_light((float(rng.uniform(-100, 100)), 40.0, float(rng.uniform(-100, 100))), 30.0, 60.0, tint)
+                                       for _ in range(n - 1)]
+    a = some_lights(40, (1.0, 0.2, 0.2))
+    b = [vr.reference_sun()] + [vr.point_light(tuple(l.position), 30.0, 60.0, (0.2, 0.2, 1.0)) for l in a[1:]]   # same places, other colour
+    c = a[:17]
+    frames = []
+    for lights in (a, b, c, a, vr.light_array(b)):
+        tiled.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+        frames.append(hdr.download().copy())
+    tiled.Status()
+    assert np.array_equal(frames[0], frames[3]) and np.array_equal(frames[1], frames[4])
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[0], frames[2])
+    for got_bits, lights in ((frames[1], b), (frames[2], c)):
+        got = oracle.half_to_float(got_bits).astype(np.float64)
+        ref = oracle.deferred(v, gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM, f32=True)
+        assert np.sqrt(np.mean((got[..., :3] - ref[..., :3]) ** 2)) <= 1e-4
+    hdr.close(); rt.close()
+
+
 def test_cpp_allgather_example_through_rccl(product_lib, tmp_path):
     """SURVEY 8b's vr_frame_allgather through the C ABI with a real RCCL communicator (one rank per visible device;
     world size 1 on a one-GPU box): histogram all-reduce, all-gather of RGB8 tiles, de-tile; the assembled frame equals

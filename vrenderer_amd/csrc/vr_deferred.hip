@@ -794,7 +794,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     VR_HIP(hipSetDevice(ctx->device));
     if ((size_t)num_lights > ctx->light_capacity) {
         VR_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_lights); ctx->d_lights = nullptr; ctx->light_capacity = 0;
+        (void)hipFree(ctx->d_lights); ctx->d_lights = nullptr; ctx->light_capacity = 0; ctx->h_lights_on_device.clear();
         const size_t cap = (size_t)num_lights < 1024 ? 1024 : (size_t)num_lights;
         VR_HIP(hipMalloc(&ctx->d_lights, cap * sizeof(DevLight)));
         ctx->light_capacity = cap;
@@ -802,7 +802,14 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     if (!ctx->d_flags) { VR_HIP(hipMalloc(&ctx->d_flags, 64)); VR_HIP(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream)); }
     ctx->h_lights.resize((size_t)num_lights);
     for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i], false); if (rc) return rc; }
-    if (num_lights) VR_HIP(hipMemcpyAsync(ctx->d_lights, ctx->h_lights.data(), (size_t)num_lights * sizeof(DevLight), hipMemcpyHostToDevice, ctx->stream));
+    // a scene's light list rarely changes between frames: upload only when it differs from what the device holds
+    const size_t light_bytes = (size_t)num_lights * sizeof(DevLight);
+    if (num_lights && (ctx->h_lights_on_device.size() != (size_t)num_lights
+                       || memcmp(ctx->h_lights_on_device.data(), ctx->h_lights.data(), light_bytes) != 0)) {
+        ctx->h_lights_on_device.clear();
+        VR_HIP(hipMemcpyAsync(ctx->d_lights, ctx->h_lights.data(), light_bytes, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h_lights_on_device = ctx->h_lights;
+    }
     DeferredArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < 16; i++) a.c2w[i] = view->clip_to_world[i];

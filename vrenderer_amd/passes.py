@@ -471,12 +471,18 @@ class CascadedShadowMap:
         self.targets.close()
 
 
-class TiledDeferredLightingPass(DeferredLightingPass):
-    """DeferredLightingPass for many lights (BASELINE config 5): per-tile LDS light culling."""
+def light_array(lights):
+    """The contiguous vr_light[] the C ABI takes, built once: a host that keeps its lights in such an array (as the
+    reference keeps them in its scene graph) does not convert a Python list per frame.  Render() accepts either."""
+    return lights if isinstance(lights, C.Array) else (Light * max(len(lights), 1))(*lights)
 
-    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None):
-        n = len(lights)
-        arr = (Light * max(n, 1))(*lights)
+
+class TiledDeferredLightingPass(DeferredLightingPass):
+    """DeferredLightingPass for many lights (BASELINE config 5): light lists per 32x32 screen tile."""
+
+    def Render(self, view, render_targets, lights, ambient_top, ambient_bottom, output, partition=None, num_lights=None):
+        n = len(lights) if num_lights is None else num_lights
+        arr = light_array(lights)
         check(self.ctx.lib.vr_deferred_light_tiled(self.ctx.handle, C.byref(view), render_targets.handle, arr, n,
                                                    _f3(ambient_top), _f3(ambient_bottom), output.handle,
                                                    C.byref(partition) if partition is not None else None),
