@@ -265,12 +265,15 @@ VR_API int  vr_deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* 
                               const float ambient_top[3], const float ambient_bottom[3],
                               vr_image* hdr_out, const vr_partition* part);
 
-/* The same pass for many lights (BASELINE config 5: 1024 point lights): per 32x32 screen tile the
- * lights are culled against the tile's world-space bounds into an LDS list, then every pixel
- * shades only that list.  Same inputs/outputs as vr_deferred_light; up to 65536 lights in all and
+/* The same pass for many lights (BASELINE config 5: 1024 point lights): a culling kernel tests the
+ * lights against the world-space bounds of every 128x128 macro tile and of its sixteen 32x32 light
+ * tiles (frustum cells over the tiles' depth ranges) and leaves one list per light tile; the shading
+ * kernel walks only that list.  Same inputs/outputs as vr_deferred_light; up to 65536 lights in all and
  * VR_TILE_LIGHT_CAP lights per tile after culling.  A tile that keeps more drops the excess (in
  * light order) and raises a device-side flag; the launch stays asynchronous, so the condition is
- * reported by vr_deferred_tiled_status. */
+ * reported by vr_deferred_tiled_status.  The light array is uploaded only when it differs from the
+ * one the previous call left on the device.  Device memory: (w/32) x (h/32) lists of
+ * min(num_lights, VR_TILE_LIGHT_CAP) + 1 words, kept by the context. */
 #define VR_TILE_LIGHT_CAP 1024
 VR_API int  vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb,
                                     const vr_light* lights, int32_t num_lights,
