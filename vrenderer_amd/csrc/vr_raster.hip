@@ -1133,7 +1133,6 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     VR_PROF_MARK(5);
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
-    const bool vec_ok = (a.w & 3) == 0;
 #ifdef VR_QUAD_U8
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quad, (short)0, (int)hm.quad_bytes, 0x00020000);
 #else
@@ -1144,10 +1143,15 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
 #else
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
 #endif
+    // A lane owns a column of four pixels, the lanes of a wave are neighbouring columns: one texel fetch of the wave then
+    // touches adjacent texels (8 lanes per 128-byte line where the terrain is minified) instead of every fourth one, as it
+    // did when a lane owned four pixels of a row.  The L1 is what this phase runs against - its tag look-ups were busy
+    // 63 % of the kernel's cycles plus 30 % stalled (TCP_TOTAL_CACHE_ACCESSES, TCP_PENDING_STALL_CYCLES), 22 look-ups per
+    // fetch instruction - not the vector pipes.
     for (int g = tid; g < TILE * TILE / 4; g += 256) {
-        const int ly = g / (TILE / 4), lx0 = (g % (TILE / 4)) * 4;
-        const int gy = oy + ly, gx0 = ox + lx0;
-        if (gy >= a.h || gx0 >= a.w) continue;
+        const int lx = g % TILE, ly0 = (g / TILE) * 4;
+        const int gx = ox + lx, gy0 = oy + ly0;
+        if (gy0 >= a.h || gx >= a.w) continue;
         uint32_t covered = 0;
         float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
         uint32_t prev = 0xffffffffu;
@@ -1160,20 +1164,18 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         // (deliberately not initialised: the first covered pixel of a group always loads its record - prev matches no key -
         // and zeroing 22 registers per group is 6 instructions per pixel)
         bool dok;
-        double d1, d2, sx1, sx2;
-        const double pxd = (double)gx0 + 0.5, pyd = (double)gy + 0.5;
+        double d1, d2, sy1, sy2;
+        const double pxd = (double)gx + 0.5, pyd = (double)gy0 + 0.5;
         float ia, iw0, iw1, iw2, wx0, wx1, wx2, wz0, wz1, wz2;
         float ddenx, ddeny, nxx, nzx, nxy, nzy;
-        // the group's four visibility words in one go (two 16-byte LDS reads ahead of the per-pixel control flow)
-        typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
-        const u64x2v k01 = *reinterpret_cast<const u64x2v*>(&vis[ly * TILE + lx0]), k23 = *reinterpret_cast<const u64x2v*>(&vis[ly * TILE + lx0 + 2]);
-        const unsigned long long keys[4] = { k01.x, k01.y, k23.x, k23.y };
+        // the column's four visibility words ahead of the per-pixel control flow
+        const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
             dep[k] = __uint_as_float((uint32_t)(key >> 32)); dif[k] = 0; nn0[k] = 0; nn1[k] = 0;
-            if (low == 0xffffffffu || gx0 + k >= a.w) continue;
+            if (low == 0xffffffffu || gy0 + k >= a.h) continue;
             covered |= 1u << k;
             if (a.depth_only) continue;
             if (low != prev) {                                    // neighbours usually share the triangle
@@ -1181,10 +1183,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 const uint4 g5 = rp[5], g6 = rp[6], g7 = rp[7], g8 = rp[8];
                 const double2 ea = reinterpret_cast<const double2*>(rp)[9], eb = reinterpret_cast<const double2*>(rp)[10],
                               ec = reinterpret_cast<const double2*>(rp)[11];
-                // edge values at the group's first pixel centre (gx0 + 0.5, gy + 0.5) in pixel units: E = 256 A x + 256 B y + C
-                sx1 = ea.x; sx2 = eb.y;
-                d1 = __builtin_fma(sx1, pxd, __builtin_fma(ea.y, pyd, eb.x));
-                d2 = __builtin_fma(sx2, pxd, __builtin_fma(ec.x, pyd, ec.y));
+                // edge values at the column's first pixel centre (gx + 0.5, gy0 + 0.5) in pixel units: E = 256 A x + 256 B y + C
+                sy1 = ea.y; sy2 = ec.x;
+                d1 = __builtin_fma(ea.x, pxd, __builtin_fma(sy1, pyd, eb.x));
+                d2 = __builtin_fma(eb.y, pxd, __builtin_fma(sy2, pyd, ec.y));
                 dok = d1 == d1;                                  // NaN: a giant triangle, exact only in int64
                 iw0 = __uint_as_float(g5.x); iw1 = __uint_as_float(g5.y); iw2 = __uint_as_float(g5.z); ddenx = __uint_as_float(g5.w);
                 wx0 = __uint_as_float(g6.x); wx1 = __uint_as_float(g6.y); wx2 = __uint_as_float(g6.z); ddeny = __uint_as_float(g6.w);
@@ -1193,10 +1195,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 prev = low;
             }
             float fe1, fe2;
-            if (dok) { fe1 = (float)__builtin_fma(sx1, (double)k, d1); fe2 = (float)__builtin_fma(sx2, (double)k, d2); }
+            if (dok) { fe1 = (float)__builtin_fma(sy1, (double)k, d1); fe2 = (float)__builtin_fma(sy2, (double)k, d2); }
             else {
                 const uint4 g1 = rp[1], g2 = rp[2];
-                const int32_t PX = (gx0 + k) * 256 + 128, PY = gy * 256 + 128;
+                const int32_t PX = gx * 256 + 128, PY = (gy0 + k) * 256 + 128;
                 fe1 = (float)edge_eval((int32_t)g1.x, (int32_t)g1.y, rec_c(g1), PX, PY);
                 fe2 = (float)edge_eval((int32_t)g2.x, (int32_t)g2.y, rec_c(g2), PX, PY);
             }
@@ -1221,46 +1223,32 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             }
             pixel_shader<SAME>(a, hm, al, rq, rc, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
-        const size_t pix = (size_t)gy * a.w + gx0;
-        const int npx = min(4, a.w - gx0);
-        const uint32_t all = (1u << npx) - 1u;
-        if (!a.assume_cleared && covered == 0) continue;          // nothing of this group was drawn
-        if (vec_ok && (covered == all || a.assume_cleared)) {
-            // every pixel of the group is defined: drawn, or the clear value
-            // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
-            // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
-            // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
-            // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
-            // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
-            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-#define ST4(ptr, a_, b_, c_, d_) do { u4 v_ = { (a_), (b_), (c_), (d_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u4*>(ptr)); \
-                                      else *reinterpret_cast<u4*>(ptr) = v_; } while (0)
-            ST4(g_depth + pix, __float_as_uint(dep[0]), __float_as_uint(dep[1]), __float_as_uint(dep[2]), __float_as_uint(dep[3]));
-            if (!a.depth_only) {
-                uint32_t sp[4];
+        if (!a.assume_cleared && covered == 0) continue;          // nothing of this column was drawn
+        // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
+        // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
+        // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
+        // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
+        // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
+        // A wave's store covers 64 (32) neighbouring pixels of a row: 256 contiguous bytes per 4-byte plane.
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+#define ST1(ptr, v) do { if (TILE == 64) __builtin_nontemporal_store((v), (ptr)); else *(ptr) = (v); } while (0)
+#define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); \
+                              else *reinterpret_cast<u2*>(ptr) = v_; } while (0)
 #pragma unroll
-                for (int k = 0; k < 4; k++) sp[k] = (covered >> k) & 1u ? spec_const : 0u;
-                ST4(g_diff + pix, dif[0], dif[1], dif[2], dif[3]);
-                ST4(g_spec + pix, sp[0], sp[1], sp[2], sp[3]);
-                ST4(g_nrm + pix, nn0[0], nn1[0], nn0[1], nn1[1]);
-                ST4(g_nrm + pix + 2, nn0[2], nn1[2], nn0[3], nn1[3]);
-                ST4(g_emi + pix, 0u, 0u, 0u, 0u);
-                ST4(g_emi + pix + 2, 0u, 0u, 0u, 0u);
-            }
-#undef ST4
-        } else {
-            for (int k = 0; k < npx; k++) {
-                const bool c = (covered >> k) & 1u;
-                if (!c && !a.assume_cleared) continue;            // keep what the target holds
-                g_depth[pix + k] = dep[k];
-                if (!a.depth_only) {
-                    g_diff[pix + k] = dif[k];
-                    g_spec[pix + k] = c ? spec_const : 0u;
-                    g_nrm[pix + k] = make_uint2(nn0[k], nn1[k]);
-                    g_emi[pix + k] = make_uint2(0u, 0u);
-                }
+        for (int k = 0; k < 4; k++) {
+            const bool c = (covered >> k) & 1u;
+            if (gy0 + k >= a.h || (!c && !a.assume_cleared)) continue;       // keep what the target holds
+            const size_t pix = (size_t)(gy0 + k) * a.w + gx;
+            ST1(g_depth + pix, dep[k]);
+            if (!a.depth_only) {
+                ST1(g_diff + pix, dif[k]);
+                ST1(g_spec + pix, c ? spec_const : 0u);
+                ST2(g_nrm + pix, nn0[k], nn1[k]);
+                ST2(g_emi + pix, 0u, 0u);
             }
         }
+#undef ST1
+#undef ST2
     }
     VR_PROF_MARK(6);
 }
