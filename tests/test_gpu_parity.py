@@ -754,6 +754,38 @@ def test_full_size_8k_frame_against_the_oracle(scene2048, oracle, gpu_ctx):
     hdr.close(); rt.close()
 
 
+def test_odd_sized_frame_on_64_pixel_tiles_against_the_oracle(scene2048, oracle, gpu_ctx):
+    """5001 x 3343 (neither a multiple of 4; 79 x 53 tiles of 64 pixels, the last column 9 and the last row 15 pixels
+    wide): the tile pass's column-of-four resolve and its per-row stores at the frame's edges.  Every G-buffer plane
+    bit-exact vs the oracle, once fused-clear and once over a cleared target whose depth plane already holds a near
+    wall in the left half (what the wall hides must keep its cleared planes)."""
+    from vrenderer_amd.scene import flythrough_camera
+    W, H = 5001, 3343
+    tp = scene2048["tp"]
+    v = vr.make_view(*flythrough_camera(100), W, H)
+    rt = vr.RenderTargets(gpu_ctx).Init(W, H)
+    gb = oracle.GBufferHost(W, H)
+    for fused in (True, False):
+        rp = vr.default_render_params(400.0, assume_cleared=1 if fused else 0)
+        rt.Clear()
+        gb.clear()
+        if not fused:
+            wall = np.ones((H, W), np.float32)
+            wall[:, :W // 2] = 0.9990
+            rt.upload("depth", wall)
+            gb.depth[...] = wall
+        tp.Render(v, v, rt, rp)
+        scene2048["ot"].render(v, gb, rp)
+        for name, ref in (("depth", gb.depth.view(np.uint32)), ("diffuse", gb.diffuse), ("specular", gb.specular),
+                          ("normals", gb.normals), ("emissive", gb.emissive)):
+            got = rt.download(name)
+            if name == "depth":
+                got = got.view(np.uint32)
+            assert np.array_equal(got, ref), f"{name} (fused={fused}): {int((got != ref).sum())} entries differ"
+        assert (gb.depth < 1.0).mean() > 0.5
+    rt.close()
+
+
 def test_full_size_4k_frame_against_the_oracle(scene2048, oracle, gpu_ctx):
     """BASELINE config 3's resolution (3840x2160, 32-pixel raster tiles, full-quadtree terrain, flythrough frame 75):
     every G-buffer plane of the whole frame bit-exact vs the oracle, HDR per-channel RMS <= 1e-4, Clear+Render equals
