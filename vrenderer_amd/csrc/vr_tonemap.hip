@@ -53,8 +53,11 @@ __device__ __forceinline__ float tm_exp2_pinned(float x)
 }
 
 // One pixel into the workgroup's LDS histogram.  Neighbouring pixels have similar luminance, so a wave's
-// 64 atomics would pile onto one or two addresses: s_hist is the lane's own copy out of kHistCopies.
-constexpr int kHistCopies = 16;
+// 64 atomics would pile onto one or two addresses: s_hist is the lane's own copy out of kHistCopies (two lanes of a
+// wave per copy), and the copies are kHistStride = bins + 1 words apart so that equal bins of different copies fall
+// on different LDS banks.  The grid is at most kHistBlocks workgroups: every workgroup ends with one global atomic per
+// bin, and 4096 of them cost more than binning an eighth of an 8K frame (27 us of the 28 a rank's share took).
+constexpr int kHistCopies = 32, kHistStride = VR_TONEMAP_BINS + 1, kHistBlocks = 1024;
 __device__ __forceinline__ void tm_bin_pixel(uint32_t* __restrict__ s_hist, const TmArgs& a, float r, float g, float b)
 {
     const float lum = tm_luminance(r, g, b);
@@ -136,9 +139,9 @@ template <bool PACKED>
 __global__ __launch_bounds__(256) void k_tm_histogram(TmArgs a, const void* __restrict__ src, const int32_t* __restrict__ owned_tiles,
                                                        size_t num_blocks, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t s_all[kHistCopies * VR_TONEMAP_BINS];
-    for (int i = threadIdx.x; i < kHistCopies * VR_TONEMAP_BINS; i += 256) s_all[i] = 0u;
-    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * VR_TONEMAP_BINS;
+    __shared__ uint32_t s_all[kHistCopies * kHistStride];
+    for (int i = threadIdx.x; i < kHistCopies * kHistStride; i += 256) s_all[i] = 0u;
+    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * kHistStride;
     __syncthreads();
     for (size_t blk = blockIdx.x; blk < num_blocks; blk += gridDim.x) {
         const QuadPos q = quad_pos<PACKED>(a, owned_tiles, blk, (int)threadIdx.x);
@@ -152,16 +155,16 @@ __global__ __launch_bounds__(256) void k_tm_histogram(TmArgs a, const void* __re
     __syncthreads();
     uint32_t v = 0u;
 #pragma unroll
-    for (int c = 0; c < kHistCopies; c++) v += s_all[c * VR_TONEMAP_BINS + threadIdx.x];
+    for (int c = 0; c < kHistCopies; c++) v += s_all[c * kHistStride + threadIdx.x];
     if (v != 0u) atomicAdd(&hist[threadIdx.x], v);
 }
 
 // any width: one pixel per lane, row-major RGBA16F
 __global__ __launch_bounds__(256) void k_tm_histogram_scalar(TmArgs a, const uint2* __restrict__ src, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t s_all[kHistCopies * VR_TONEMAP_BINS];
-    for (int i = threadIdx.x; i < kHistCopies * VR_TONEMAP_BINS; i += 256) s_all[i] = 0u;
-    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * VR_TONEMAP_BINS;
+    __shared__ uint32_t s_all[kHistCopies * kHistStride];
+    for (int i = threadIdx.x; i < kHistCopies * kHistStride; i += 256) s_all[i] = 0u;
+    uint32_t* s_hist = s_all + (threadIdx.x & (kHistCopies - 1)) * kHistStride;
     __syncthreads();
     const size_t n = (size_t)a.w * a.h;
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void k_tm_histogram_scalar(TmArgs a, const uin
     __syncthreads();
     uint32_t v = 0u;
 #pragma unroll
-    for (int c = 0; c < kHistCopies; c++) v += s_all[c * VR_TONEMAP_BINS + threadIdx.x];
+    for (int c = 0; c < kHistCopies; c++) v += s_all[c * kHistStride + threadIdx.x];
     if (v != 0u) atomicAdd(&hist[threadIdx.x], v);
 }
 
@@ -411,14 +414,14 @@ extern "C" VR_API int vr_tonemap_add_frame_to_histogram(vr_tonemap* tm, const vr
     VrKernelScope ks(ctx, VR_K_TM_HISTOGRAM);
     if (part) {
         if (blocks > 0)
-            hipLaunchKernelGGL(k_tm_histogram<true>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
+            hipLaunchKernelGGL(k_tm_histogram<true>, dim3((unsigned)(blocks < (size_t)kHistBlocks ? blocks : (size_t)kHistBlocks)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
                                pt->d_owned_tiles, blocks, tm->d_hist);
     } else if (w % 4 == 0) {
-        hipLaunchKernelGGL(k_tm_histogram<false>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
+        hipLaunchKernelGGL(k_tm_histogram<false>, dim3((unsigned)(blocks < (size_t)kHistBlocks ? blocks : (size_t)kHistBlocks)), dim3(256), 0, ctx->stream, a, (const void*)hdr->data,
                            (const int32_t*)nullptr, blocks, tm->d_hist);
     } else {
         const size_t b = ((size_t)w * h + 255) / 256;
-        hipLaunchKernelGGL(k_tm_histogram_scalar, dim3((unsigned)(b < 4096 ? b : 4096)), dim3(256), 0, ctx->stream, a, (const uint2*)hdr->data, tm->d_hist);
+        hipLaunchKernelGGL(k_tm_histogram_scalar, dim3((unsigned)(b < (size_t)kHistBlocks ? b : (size_t)kHistBlocks)), dim3(256), 0, ctx->stream, a, (const uint2*)hdr->data, tm->d_hist);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;
