@@ -535,6 +535,25 @@ def main():
                     "frac": round(ach / peak, 4), "insts_per_launch": sq[name]["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
                     "source": sq_file}
 
+        def roof_l1(name):
+            """The tile pass's other bound: the L1's tag look-ups (one cache line per clock per CU).  achieved = look-ups per
+            launch (TCP_TOTAL_CACHE_ACCESSES from the committed PMC pass of the 8K tile pass) / the live HIP-event duration;
+            peak = 256 L1s x 2.4 GHz.  Only quoted for the frame the counters were collected on (8K, unsplit)."""
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_tcp.json")) as f:
+                    tcp = json.load(f)
+            except OSError:
+                return None
+            if name not in timings or name not in tcp or (W, H) != (7680, 4320) or part is not None:
+                return None
+            ms, n = timings[name]
+            avg_s = ms / n * 1e-3
+            ach = tcp[name]["TCP_TOTAL_CACHE_ACCESSES"] / avg_s / 1e9
+            peak = 256 * 2.4
+            return {"kernel": name, "bound": "l1-tags", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G look-ups/s",
+                    "frac": round(ach / peak, 4), "lookups_per_launch": tcp[name]["TCP_TOTAL_CACHE_ACCESSES"],
+                    "pending_stall_cycles_per_launch": tcp[name]["TCP_PENDING_STALL_CYCLES"], "source": "profiles/r02_pmc_tcp.json"}
+
         roof_deferred = roof(light_kernel, DEFERRED_BYTES_PER_PX, owned_px)
         roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
         out = {
@@ -556,6 +575,7 @@ def main():
             "roofline": roof_deferred,
             "roofline_gbuffer_fill": roof_raster,
             "roofline_valu": [r for r in (roof_valu("k_raster"), roof_valu(light_kernel) if tiled else None) if r],
+            "roofline_l1": roof_l1("k_raster"),
             "dominant_kernel_by_time": dominant,
             "kernels": kern,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
