@@ -622,18 +622,6 @@ __device__ __forceinline__ float div_ws(const RasterArgs& a, float s)
 }
 __device__ __forceinline__ float to_uv(const RasterArgs& a, float x) { return div_ws(a, x + a.world_size * 0.5f); }
 
-__device__ __forceinline__ void srgb_filter(uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11, const BilinearSetup& s,
-                                            const float* __restrict__ lut, float out[3])
-{
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float t00 = lut[(p00 >> (8 * c)) & 255u], t10 = lut[(p10 >> (8 * c)) & 255u];
-        const float t01 = lut[(p01 >> (8 * c)) & 255u], t11 = lut[(p11 >> (8 * c)) & 255u];
-        const float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
-        out[c] = top + (bot - top) * s.fy;
-    }
-}
-
 // One axis of a bilinear footprint: texel-space coordinate -> integer floor (clamped to [-1, n], as the quad table is
 // indexed) and fraction.  Same operations as quad_tap / vr_bilinear_setup, once per distinct coordinate.
 struct Axis { int i; float f; };
@@ -644,12 +632,6 @@ __device__ __forceinline__ Axis tap_axis(int n, float t)
     Axis r; r.f = x - xf;
     r.i = (int)vr_clampf(xf, -1.0f, (float)n);
     return r;
-}
-__device__ __forceinline__ float quad_filter_f(uint32_t e, float fx, float fy, const float* __restrict__ r8)
-{
-    const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
-    const float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
-    return top + (bot - top) * fy;
 }
 // NaN never reaches the normal's encode (the vector is normalised from a length >= 0.2): clamp, scale, round half away
 __device__ __forceinline__ uint32_t snorm16_finite(float v)
@@ -663,31 +645,19 @@ __device__ __forceinline__ uint32_t snorm16_finite(float v)
 // albedo footprint is the floor / fraction pair the height taps at the unshifted u and v already computed.
 template <bool SAME>
 __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc,
-                                             const float* __restrict__ lut, const float* __restrict__ r8, const uint32_t* __restrict__ qoff,
-                                             const uint32_t* __restrict__ aoff, int lvl_h, int lvl_c, float ua, float ub, float va, float vb,
+                                             const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, int lvl_h, int lvl_c, float ua, float ub, float va, float vb,
                                              float u0, float v0, float u, float v, float hgt[4], float col[3])
 {
     const int w = max(1, hm.w0 >> lvl_h), h = max(1, hm.h0 >> lvl_h);
     const uint32_t q = qoff[lvl_h], c = aoff[lvl_c];             // dword offset of the quad table, byte offset of the albedo level
     const Axis xa = tap_axis(w, ua), xb = tap_axis(w, ub), x0 = tap_axis(w, u0), y0 = tap_axis(h, v0), ya = tap_axis(h, va), yb = tap_axis(h, vb);
     const int r0 = __mul24(y0.i + 1, w + 2) + 1, ra = __mul24(ya.i + 1, w + 2) + 1, rb = __mul24(yb.i + 1, w + 2) + 1;
-#ifdef VR_QUAD_U8
-#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b32(rq, (q + (uint32_t)(i)) << 2, 0, 0)
-    const uint32_t e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
-#else
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, (q + (uint32_t)(i)) << 4, 0, 0)
     const u32x4 e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
-#endif
-#ifdef VR_ALBEDO_U8
-#define LDC(i) __builtin_amdgcn_raw_buffer_load_b32(rc, c + ((uint32_t)(i) << 2), 0, 0)
-    uint32_t p00, p10, p01, p11;
-#else
-    typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
     const uint32_t c4 = c << 2;                                   // the decoded chain: 16 B per texel, levels at 4 x the byte offset
 #define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, ((uint32_t)(i) << 4) + c4, 0, 0)
-    u32x4c p00, p10, p01, p11;
-#endif
+    u32x4 p00, p10, p01, p11;
     float cfx, cfy;
     if (SAME) {
         const int cx0 = vr_clampi(x0.i, 0, w - 1), cx1 = vr_clampi(x0.i + 1, 0, w - 1), cy0 = vr_clampi(y0.i, 0, h - 1), cy1 = vr_clampi(y0.i + 1, 0, h - 1);
@@ -701,27 +671,17 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     }
 #undef LDQ
 #undef LDC
-#ifdef VR_QUAD_U8
-    hgt[0] = quad_filter_f(e0, xa.f, y0.f, r8); hgt[1] = quad_filter_f(e1, xb.f, y0.f, r8);
-    hgt[2] = quad_filter_f(e2, x0.f, ya.f, r8); hgt[3] = quad_filter_f(e3, x0.f, yb.f, r8);
-#else
     // entry = (t00, t10 - t00, t01, t11 - t01): top = t00 + (t10 - t00) * fx, bot likewise, then across y
 #define QF(e, fx, fy) ({ const float top_ = __uint_as_float((e).x) + __uint_as_float((e).y) * (fx), bot_ = __uint_as_float((e).z) + __uint_as_float((e).w) * (fx); \
                          top_ + (bot_ - top_) * (fy); })
     hgt[0] = QF(e0, xa.f, y0.f); hgt[1] = QF(e1, xb.f, y0.f); hgt[2] = QF(e2, x0.f, ya.f); hgt[3] = QF(e3, x0.f, yb.f);
 #undef QF
-#endif
-#ifdef VR_ALBEDO_U8
-    BilinearSetup fs; fs.fx = cfx; fs.fy = cfy; fs.i00 = fs.i10 = fs.i01 = fs.i11 = 0;
-    srgb_filter(p00, p10, p01, p11, fs, lut, col);
-#else
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float t00 = __uint_as_float(p00[k]), t10 = __uint_as_float(p10[k]), t01 = __uint_as_float(p01[k]), t11 = __uint_as_float(p11[k]);
         const float top = t00 + (t10 - t00) * cfx, bot = t01 + (t11 - t01) * cfx;
         col[k] = top + (bot - top) * cfy;
     }
-#endif
 }
 
 // main_ps (terrain_ps.hlsl:45-82) -> encoded render-target texels.  qoff / aoff: LDS copies of the
@@ -732,8 +692,7 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
 // 32-bit byte offset (1 VALU) instead of a 64-bit pointer sum (3), and an out-of-range offset reads 0 instead of faulting.
 template <bool SAME>
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq,
-                                             __amdgpu_buffer_rsrc_t rc, const float* __restrict__ lut,
-                                             const float* __restrict__ thr, const uint8_t* __restrict__ enc, const float* __restrict__ r8,
+                                             __amdgpu_buffer_rsrc_t rc, const float* __restrict__ thr, const uint8_t* __restrict__ enc,
                                              const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
@@ -746,7 +705,7 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     const float offset = 0.1f;                                                              // :59
     const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset), u0 = u + 0.0f, v0 = v + 0.0f;
     float hgt[4], col[3];
-    sample_level<SAME>(hm, al, rq, rc, lut, r8, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
+    sample_level<SAME>(hm, al, rq, rc, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
     if (__any(lh.f > 0.0f || lc.f > 0.0f)) {
@@ -757,7 +716,7 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
         float xa = ua, xb = ub, ya = va, yb = vb, x0 = u0, y0 = v0, xu = u, yv = v;
         asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ya), "+v"(yb), "+v"(x0), "+v"(y0), "+v"(xu), "+v"(yv));
         float g[4], cb[3];
-        sample_level<SAME>(hm, al, rq, rc, lut, r8, qoff, aoff, l1h, l1c, xa, xb, ya, yb, x0, y0, xu, yv, g, cb);
+        sample_level<SAME>(hm, al, rq, rc, qoff, aoff, l1h, l1c, xa, xb, ya, yb, x0, y0, xu, yv, g, cb);
         hgt[0] = hgt[0] + (g[0] - hgt[0]) * lh.f; hgt[1] = hgt[1] + (g[1] - hgt[1]) * lh.f;
         hgt[2] = hgt[2] + (g[2] - hgt[2]) * lh.f; hgt[3] = hgt[3] + (g[3] - hgt[3]) * lh.f;
 #pragma unroll
@@ -941,19 +900,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                                                  const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
-                                                 const float* __restrict__ lut_g, const float* __restrict__ thr_g,
+                                                 const float* __restrict__ thr_g,
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const)
 {
     __shared__ unsigned long long vis[TILE * TILE];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float thr[kThrTabSize];
-    // the byte -> float tables are only needed by the variants that still read 8-bit texels (A/B builds)
-#if defined(VR_QUAD_U8) || defined(VR_ALBEDO_U8)
-    __shared__ float lut[256];
-    __shared__ float r8[256];
-#else
-    const float* const lut = nullptr; const float* const r8 = nullptr;
-#endif
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
@@ -964,9 +916,6 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
     thr[tid] = thr_g[tid];
-#if defined(VR_QUAD_U8) || defined(VR_ALBEDO_U8)
-    lut[tid] = lut_g[tid]; r8[tid] = (float)tid / 255.0f;
-#endif
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     if (a.assume_cleared && ox + TILE <= a.w && oy + TILE <= a.h) {       // interior tile of a cleared target: one constant
@@ -1133,16 +1082,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     VR_PROF_MARK(5);
 
     // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
-#ifdef VR_QUAD_U8
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quad, (short)0, (int)hm.quad_bytes, 0x00020000);
-#else
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
-#endif
-#ifdef VR_ALBEDO_U8
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.base, (short)0, (int)al.chain_bytes, 0x00020000);
-#else
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
-#endif
     // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K)
     const uint64_t gb_span = (uint64_t)(reinterpret_cast<const char*>(g_emi + (size_t)a.w * a.h) - reinterpret_cast<const char*>(g_depth));
     const uint64_t od = (uint64_t)(reinterpret_cast<const char*>(g_diff) - reinterpret_cast<const char*>(g_depth));
@@ -1230,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 p.dwxdx = (nxx - p.wx * ddenx) * r; p.dwzdx = (nzx - p.wz * ddenx) * r;
                 p.dwxdy = (nxy - p.wx * ddeny) * r; p.dwzdy = (nzy - p.wz * ddeny) * r;
             }
-            pixel_shader<SAME>(a, hm, al, rq, rc, lut, thr, enc, r8, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
+            pixel_shader<SAME>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
         }
         if (!a.assume_cleared && covered == 0) continue;          // nothing of this column was drawn
         // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
@@ -1476,7 +1417,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
                                       : (a.wireframe ? k_raster<true, 64, false> : (same ? k_raster<false, 64, true> : k_raster<false, 64, false>));
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_lut, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
     }
     if (pass_stop) g.raster_done = pass_stop;
