@@ -530,18 +530,18 @@ __device__ __forceinline__ bool sphere_touches(const float* __restrict__ box, co
 __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
                                                      const float* __restrict__ g_depth, int macro_x,
                                                      const int32_t* __restrict__ owned_tiles, uint32_t* __restrict__ lists, int stride,
-                                                     int tiles32_x, int tiles32_y, uint32_t* __restrict__ overflow_flag)
+                                                     int tiles32_x, int tiles32_y, uint32_t* __restrict__ overflow_flag,
+                                                     uint32_t* __restrict__ macro_scratch)
 {
     __shared__ uint32_t s_dmin[kSubTiles], s_dmax[kSubTiles];   // bits of non-negative floats: ordered like the floats
     __shared__ float s_box[kSubTiles + 1][6];                   // the light tiles' boxes, then the macro tile's
-    __shared__ uint32_t s_wave_count[4][kSubTiles];
-    __shared__ uint32_t s_count[kSubTiles];
+    __shared__ uint32_t s_kept[4];
     __shared__ uint32_t s_covered;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = owned_tiles ? owned_tiles[blockIdx.x] : (int)blockIdx.x;
     const int ty = tile / macro_x, tx = tile - ty * macro_x;
     const int x0 = tx * kMacroTile, y0 = ty * kMacroTile;
-    if (tid < kSubTiles) { s_dmin[tid] = 0x7f800000u; s_dmax[tid] = 0u; s_count[tid] = 0u; }
+    if (tid < kSubTiles) { s_dmin[tid] = 0x7f800000u; s_dmax[tid] = 0u; }
     if (tid == 0) s_covered = 0u;
     __syncthreads();
     // ---- depth range per light tile: lane = 4 px of a row; a wave holds two rows of the macro tile per step
@@ -623,52 +623,75 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
         const int gx = tx * kSubSide + (lane & 3), gy = ty * kSubSide + (lane >> 2);
         if (gx < tiles32_x && gy < tiles32_y) my_list = lists + (size_t)(gy * tiles32_x + gx) * stride;
     }
+    // ---- A. every wave takes a quarter of the light list and keeps, in order, the lights that touch the macro tile's box
+    // (its region of the scratch list: no synchronisation until all four are done; the next 64 lights are in flight
+    // while the current ones are tested)
+    struct Lite { float pos[3]; float inv_range; int type; };
+    auto fetch = [&](int li, int hi) { Lite l; l.pos[0] = l.pos[1] = l.pos[2] = 0.0f; l.inv_range = 0.0f; l.type = -1;
+        if (li < hi) { const DevLight& L = lights[li]; l.pos[0] = L.pos[0]; l.pos[1] = L.pos[1]; l.pos[2] = L.pos[2]; l.inv_range = L.inv_range; l.type = L.type; }
+        return l; };
+    const int quarter = (num_lights + 3) / 4;
+    const int lo_w = min(wave * quarter, num_lights), hi_w = min(lo_w + quarter, num_lights);
+    uint32_t* __restrict__ kept_list = macro_scratch + (size_t)tile * (size_t)(quarter * 4);
+    uint32_t kept = 0u;                                               // (wave-uniform)
     if (covered_mask != 0u) {
-        for (int base = 0; base < num_lights; base += 256) {
-            const int li = base + tid;
-            uint32_t mask = 0u;
-            if (li < num_lights) {
-                const DevLight L = lights[li];
-                if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) mask = covered_mask;
-                else {
-                    const float r = 1.0f / L.inv_range, r2 = (r * r) * 1.0001f;
-                    if (sphere_touches(s_box[kSubTiles], L.pos, r2)) {
-#pragma unroll
-                        for (int b = 0; b < kSubTiles; b++) mask |= sphere_touches(s_box[b], L.pos, r2) ? 1u << b : 0u;
-                    }
-                }
+        Lite cur = fetch(lo_w + lane, hi_w);
+        for (int base = lo_w; base < hi_w; base += 64) {
+            const Lite nxt = fetch(base + 64 + lane, hi_w);
+            bool keep = false;
+            if (cur.type >= 0) {
+                if (cur.type == VR_LIGHT_DIRECTIONAL || !(cur.inv_range > 0.0f)) keep = true;
+                else { const float r = 1.0f / cur.inv_range; keep = sphere_touches(s_box[kSubTiles], cur.pos, (r * r) * 1.0001f); }
             }
-            // ordered append: per light tile, this wave's survivors, then the offsets of the waves before it
-            uint32_t mine = 0u;
-#pragma unroll
-            for (int b = 0; b < kSubTiles; b++) {
-                const uint32_t c = (uint32_t)__popcll(__ballot((mask >> b) & 1u));
-                if (lane == b) mine = c;
-            }
-            if (lane < kSubTiles) s_wave_count[wave][lane] = mine;
-            __syncthreads();
-            if (__any(mask != 0u)) {
-#pragma unroll
-                for (int b = 0; b < kSubTiles; b++) {
-                    const unsigned long long m = __ballot((mask >> b) & 1u);
-                    if (m == 0ull) continue;
-                    uint32_t before = s_count[b];
-                    for (int w = 0; w < wave; w++) before += s_wave_count[w][b];
-                    uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(
-                        (uintptr_t)__shfl((unsigned long long)(uintptr_t)my_list, b));
-                    if ((mask >> b) & 1u) {
-                        const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (slot < cap) list[1u + slot] = (uint32_t)li;
-                        else atomicOr(overflow_flag, 1u);
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < kSubTiles) s_count[tid] += s_wave_count[0][tid] + s_wave_count[1][tid] + s_wave_count[2][tid] + s_wave_count[3][tid];
-            __syncthreads();
+            const unsigned long long m = __ballot(keep);
+            if (keep) kept_list[(uint32_t)lo_w + kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(base + lane);
+            kept += (uint32_t)__popcll(m);
+            cur = nxt;
         }
     }
-    if (wave == 0 && my_list) my_list[0] = min(s_count[lane], cap);
+    if (lane == 0) s_kept[wave] = kept;
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- B. one wave sorts the survivors into the sixteen light tiles' lists, in light order (ballot + popcount prefix)
+    uint32_t cnt[kSubTiles];
+#pragma unroll
+    for (int b = 0; b < kSubTiles; b++) cnt[b] = 0u;
+    for (int w = 0; w < 4; w++) {
+        const uint32_t K = s_kept[w];
+        const uint32_t* __restrict__ src = kept_list + min(w * quarter, num_lights);
+        for (uint32_t i0 = 0; i0 < K; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint32_t mask = 0u, li = 0u;
+            if (i < K) {
+                li = src[i];
+                const DevLight& L = lights[li];
+                if (L.type == VR_LIGHT_DIRECTIONAL || !(L.inv_range > 0.0f)) mask = covered_mask;
+                else {
+                    const float pos[3] = { L.pos[0], L.pos[1], L.pos[2] };
+                    const float r = 1.0f / L.inv_range, r2 = (r * r) * 1.0001f;
+#pragma unroll
+                    for (int b = 0; b < kSubTiles; b++) mask |= sphere_touches(s_box[b], pos, r2) ? 1u << b : 0u;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < kSubTiles; b++) {
+                const unsigned long long m = __ballot((mask >> b) & 1u);
+                if (m == 0ull) continue;
+                uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>((uintptr_t)__shfl((unsigned long long)(uintptr_t)my_list, b));
+                if ((mask >> b) & 1u) {
+                    const uint32_t slot = cnt[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot < cap) list[1u + slot] = li;
+                    else atomicOr(overflow_flag, 1u);
+                }
+                cnt[b] += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int b = 0; b < kSubTiles; b++) if (lane == b) mine = cnt[b];
+    if (my_list) my_list[0] = min(mine, cap);
 }
 
 #ifndef VR_TILED_PXB
@@ -829,6 +852,14 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         VR_HIP(hipMalloc(&ctx->d_light_lists, words * sizeof(uint32_t)));
         ctx->light_list_words = words;
     }
+    // per macro tile: the lights that touch its box, in four regions (one per wave of k_light_cull)
+    const size_t scratch_words = (size_t)macro_x * macro_y * (size_t)(((num_lights + 3) / 4) * 4) + 4;
+    if (scratch_words > ctx->macro_scratch_words) {
+        VR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_macro_scratch); ctx->d_macro_scratch = nullptr; ctx->macro_scratch_words = 0;
+        VR_HIP(hipMalloc(&ctx->d_macro_scratch, scratch_words * sizeof(uint32_t)));
+        ctx->macro_scratch_words = scratch_words;
+    }
     VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
     if (packed) {
         const PartTables* pt = nullptr;
@@ -838,7 +869,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (pt->num_owned > 0) {
             hipLaunchKernelGGL(k_light_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags);
+                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch);
             hipLaunchKernelGGL((k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), 0, ctx->stream, a,
                                ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
                                ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx);
@@ -846,7 +877,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         hipLaunchKernelGGL(k_light_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags);
+                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch);
         hipLaunchKernelGGL((k_deferred_tiled<false, VR_TILED_PXB>), dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
                            (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);

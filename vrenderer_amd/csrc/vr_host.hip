@@ -74,7 +74,7 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_srgb_thr); (void)hipFree(c->d_enc_tab);
-    (void)hipFree(c->d_lights); (void)hipFree(c->d_flags); (void)hipFree(c->d_light_lists);
+    (void)hipFree(c->d_lights); (void)hipFree(c->d_flags); (void)hipFree(c->d_light_lists); (void)hipFree(c->d_macro_scratch);
     for (PartTables* pt : c->part_tables) {
         (void)hipFree(pt->d_owned_tiles); (void)hipFree(pt->d_tile_slot); (void)hipFree(pt->d_raster_tiles);
         delete pt;

@@ -124,6 +124,7 @@ struct vr_context {
     hipEvent_t last_stop = nullptr;     // stop event of the most recent dispatch-stamped launch on `stream`
     // light list of vr_deferred_light_tiled
     DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights, h_lights_on_device;   // (the list d_lights holds)
+    uint32_t* d_macro_scratch = nullptr; size_t macro_scratch_words = 0;   // per macro tile: lights touching its box (k_light_cull's first stage)
     uint32_t* d_light_lists = nullptr; size_t light_list_words = 0;    // per 32x32 light tile: count + light indices (k_light_cull)
     uint32_t* d_flags = nullptr;
     // per-kernel timing (vr_timing_*): event pairs recorded on `stream`
