@@ -30,7 +30,8 @@ constexpr int kVertsPerInst = kSide * kSide; // 1089
 constexpr int kTrisPerInst = kGrid * kGrid * 2; // 2048
 constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of large frames; also the upper bound of either size
 // Tile edge of the raster / bin grid for a w x h target: 64, or 32 when 64-pixel tiles would leave the chip's
-// 1024 workgroup slots short of work (measured: 1080p tile pass 140 -> 92 us, 4K 219 -> 208, 8K 568 -> 644).
+// 1024 workgroup slots short of work (measured in round 2, 64- vs 32-pixel tiles: 1080p tile pass 144 vs 91 us, 1440p 152 vs
+// 116, 4K 190 vs 188, 5120x2880 253 vs 270, 8K far apart the other way): the switch sits just above 4K's 2040 tiles.
 // A rank of an N-way split rasterises 1/N of the tiles, scattered over a frame whose triangles stay large: 32-pixel
 // tiles pay there only once the share drops below ~1.5 launch waves (measured at 8K on one GPU: N=2 274 vs 391 us,
 // N=4 153 vs 192 us with 64- vs 32-pixel tiles, N=8 107 vs 83 us).
@@ -38,7 +39,7 @@ inline int vr_raster_tile_shift(int w, int h, int world = 1)
 {
     const long tiles64 = (long)((w + 63) / 64) * (long)((h + 63) / 64);
     if (world > 1) return tiles64 / world < 1536 ? 5 : 6;
-    return tiles64 < 4096 ? 5 : 6;
+    return tiles64 < 2560 ? 5 : 6;
 }
 constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
 constexpr int kMaxLevels = 16;
