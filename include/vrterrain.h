@@ -422,6 +422,10 @@ VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
  * [2] clipper sub-triangles, [3] clipper vertices, [4] triangles sent to the clipper, [5] bin entries,
  * [6] largest bin, [7] non-empty bins */
 VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8]);
+/* Test helper: the vertex stage's output (main_vs, terrain_vs.hlsl:35-62) of the last vr_terrain_render for `count`
+ * vertices starting at vertex `first` of the instanced draw (vertex = instance * 1089 + row * 33 + column, rows = z):
+ * six floats per vertex - o_position.xyzw (clip space) and o_vtx.pos.xz (world space).  Synchronises. */
+VR_API int vr_debug_download_vertices(vr_terrain* t, uint32_t first, uint32_t count, float* out_xyzw_wxwz);
 /* test helper: the device's linear -> sRGB8 render-target conversion applied to n host floats */
 VR_API int vr_debug_srgb_encode(vr_context* ctx, const float* in, size_t n, uint8_t* out);
 /* Test helper: sweeps every float with an exponent in [-60, 60) through the pixel shader's short reciprocal and square-root

@@ -18,10 +18,24 @@ LIB_PATH = os.path.join(_DIR, "_build", "libvroracle.so")
 _lib = None
 
 
+def _host_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return any(" fma " in (line + " ") for line in f if line.startswith("flags"))
+    except OSError:
+        return True
+
+
 def build(force=False):
+    """Builds the oracle library (with -mfma: the model's fmaf() calls become one instruction).  On a host without FMA
+    hardware the same source is built without the flag into its own file - libm's fmaf gives the identical values."""
+    global LIB_PATH
     src = os.path.join(_DIR, "vr_oracle.c")
+    nofma = not _host_has_fma()
+    if nofma:
+        LIB_PATH = os.path.join(_DIR, "_build", "libvroracle_nofma.so")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _DIR, "-B" if force else "-s"], check=True,
+        subprocess.run(["make", "-C", _DIR, "-B" if force else "-s"] + (["NOFMA=1"] if nofma else []), check=True,
                        stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -30,7 +44,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not _host_has_fma():
         build()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER

@@ -8,11 +8,25 @@
  * marked [DONUT-RECOLLECTION]: they restate Donut's published behaviour from memory
  * and *define* the model the HIP path is checked against.
  *
- * Floating-point discipline (so a GPU can reproduce results bit for bit): fp32
- * only, every expression evaluated in the written order, no FMA contraction
- * (build with -ffp-contract=off), only + - * / sqrt (all IEEE correctly rounded),
- * no libm transcendental on any per-vertex / per-pixel path.  dot3(a,b) is
+ * Floating-point discipline (so a GPU can reproduce results bit for bit): every
+ * expression is evaluated in the written order with no implicit contraction (build
+ * with -ffp-contract=off); the only operations are + - * / sqrt and the fused
+ * multiply-add WHERE IT IS WRITTEN as fmaf()/fma() (all IEEE correctly rounded), and
+ * no libm transcendental runs on any per-vertex / per-pixel path.  dot3(a,b) is
  * (a.x*b.x + a.y*b.y) + a.z*b.z everywhere.
+ *
+ * Raster model, revision 3 (round 3).  The parts of the pipeline that D3D leaves to
+ * the implementation - attribute interpolation, the sampler's address / filter
+ * arithmetic and the implicit level of detail - are stated the way GPUs execute them:
+ *   - interpolation by per-triangle PLANE EQUATIONS set up in double precision and
+ *     evaluated per pixel with two fused multiply-adds (depth, 1/w and attribute/w
+ *     are affine in screen space; fixed-function interpolators work this way);
+ *   - the sampler's `u * size - 0.5`, its lerps and the LOD's sums of squares as
+ *     fused multiply-adds (what `mad` is on every current GPU).
+ * Everything the HLSL source itself pins (uv = (pos + half) / size, uv + offset,
+ * hDx = a - b, normalize) keeps its written order.  Revisions 1-2 evaluated the same
+ * quantities from barycentrics with unfused arithmetic; the results differ in the last
+ * bits only, and the HIP path is checked against THIS file bit for bit either way.
  */
 #define _POSIX_C_SOURCE 200809L
 #include "vr_oracle.h"
@@ -165,12 +179,12 @@ static void tex_build(orc_tex* t, const uint8_t* src, int w, int h, int texel_by
 }
 static void tex_free(orc_tex* t) { for (int l = 0; l < t->levels; l++) free(t->data[l]); t->levels = 0; }
 
-/* one bilinear tap, clamp addressing, fp32 weights; out = 1 (R8) or 3 (rgb) floats */
+/* one bilinear tap, clamp addressing, fp32 weights, lerps as fused multiply-adds; out = 1 (R8) or 3 (rgb) floats */
 static void tex_bilinear(const orc_tex* t, int level, float u, float v, float out[3])
 {
     int w = t->w[level], h = t->h[level];
     const uint8_t* d = t->data[level];
-    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
     float xf = floorf(x), yf = floorf(y);
     float fx = x - xf, fy = y - yf;
     /* clamp in float first so huge / non-finite coordinates cannot overflow the int */
@@ -181,15 +195,15 @@ static void tex_bilinear(const orc_tex* t, int level, float u, float v, float ou
     if (t->texel_bytes == 1) {
         float t00 = (float)d[y0*w+x0] / 255.0f, t10 = (float)d[y0*w+x1] / 255.0f;
         float t01 = (float)d[y1*w+x0] / 255.0f, t11 = (float)d[y1*w+x1] / 255.0f;
-        float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
-        out[0] = top + (bot - top) * fy;
+        float top = fmaf(t10 - t00, fx, t00), bot = fmaf(t11 - t01, fx, t01);
+        out[0] = fmaf(bot - top, fy, top);
     } else {
         const uint8_t* p00 = d + 4*((size_t)y0*w+x0); const uint8_t* p10 = d + 4*((size_t)y0*w+x1);
         const uint8_t* p01 = d + 4*((size_t)y1*w+x0); const uint8_t* p11 = d + 4*((size_t)y1*w+x1);
         for (int c = 0; c < 3; c++) {
             float t00 = g_srgb_lut[p00[c]], t10 = g_srgb_lut[p10[c]], t01 = g_srgb_lut[p01[c]], t11 = g_srgb_lut[p11[c]];
-            float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
-            out[c] = top + (bot - top) * fy;
+            float top = fmaf(t10 - t00, fx, t00), bot = fmaf(t11 - t01, fx, t01);
+            out[c] = fmaf(bot - top, fy, top);
         }
     }
 }
@@ -207,7 +221,7 @@ static void tex_trilinear(const orc_tex* t, float lod, float u, float v, float o
     tex_bilinear(t, l0, u, v, a);
     if (f > 0.0f) {
         tex_bilinear(t, l0 + 1, u, v, b);
-        for (int c = 0; c < n; c++) out[c] = a[c] + (b[c] - a[c]) * f;
+        for (int c = 0; c < n; c++) out[c] = fmaf(b[c] - a[c], f, a[c]);
     } else {
         for (int c = 0; c < n; c++) out[c] = a[c];
     }
@@ -219,14 +233,14 @@ static void tex_trilinear(const orc_tex* t, float lod, float u, float v, float o
 static float lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
 {
     float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
-    float r2x = ax*ax + ay*ay, r2y = bx*bx + by*by;
+    float r2x = fmaf(ax, ax, ay*ay), r2y = fmaf(bx, bx, by*by);
     float r2 = r2x > r2y ? r2x : r2y;
     if (!(r2 > 1.0f)) return 0.0f;
     uint32_t bits = f2u(r2);
     int e = (int)((bits >> 23) & 255u) - 127;
     if (e >= 128) return 64.0f;                                   /* inf/nan -> coarsest */
     float t = u2f((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
-    float p = t * (1.4208646f + t * (-0.57725066f + t * 0.1563861f));
+    float p = t * fmaf(t, fmaf(t, 0.1563861f, -0.57725066f), 1.4208646f);
     return 0.5f * ((float)e + p);
 }
 
@@ -772,33 +786,57 @@ static inline int top_left(const orc_sv* a, const orc_sv* b)
     return (dy < 0) || (dy == 0 && dx > 0);
 }
 
-/* Perspective-correct interpolation of world xz at a pixel centre, and its screen-space
- * derivatives (per one-pixel step in x and y) — the analytic derivative of the same
- * interpolant, which is what Texture2D::Sample's implicit LOD is computed from here
- * (hardware takes quad finite differences; D3D leaves the method to the implementation). */
-typedef struct { float wx, wz, dwxdx, dwzdx, dwxdy, dwzdy; } orc_attr;
-static orc_attr interp(const orc_sv* v0, const orc_sv* v1, const orc_sv* v2, float inv_area, int64_t E1, int64_t E2,
-                       int64_t dE1dx, int64_t dE2dx, int64_t dE1dy, int64_t dE2dy)
+/* Fixed-function interpolation, raster model revision 3: per-triangle PLANE EQUATIONS.
+ * Depth z, q = 1/w and the attributes over w (wx/w, wz/w) are affine functions of the pixel
+ * position, so each is P(x, y) = p0 + px * (x - ax) + py * (y - ay) about an anchor pixel (ax, ay)
+ * of the triangle (the first pixel of its viewport-clamped bounding box).  The coefficients are
+ * set up ONCE per triangle in double precision from the exact integer edge functions and rounded to
+ * float; a pixel evaluates fmaf(py, dy, fmaf(px, dx, p0)) with dx, dy small exact integers.
+ * Perspective correction: attribute = (attribute/w)(x, y) * (1 / q(x, y)), IEEE division.
+ * The screen-space derivatives of the attributes - what Texture2D::Sample's implicit LOD is
+ * computed from here (hardware takes quad finite differences; D3D leaves the method to the
+ * implementation) - are the analytic derivatives of that quotient:
+ *   d(N/q)/dx = (N_x - (N/q) q_x) / q. */
+typedef struct { float p0, px, py; } orc_plane;
+typedef struct { int ax, ay; orc_plane z, q, nx, nz; } orc_planes;
+
+static orc_plane plane_of(const double l[3], const double lx[3], const double ly[3], double a0, double a1, double a2)
 {
-    float l1 = (float)E1 * inv_area, l2 = (float)E2 * inv_area;
-    float l0 = (1.0f - l1) - l2;
-    float q0 = l0 * v0->iw, q1 = l1 * v1->iw, q2 = l2 * v2->iw;
-    float den = (q0 + q1) + q2;
-    float r = 1.0f / den;
-    float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
+    orc_plane p;
+    p.p0 = (float)((l[0] * a0 + l[1] * a1) + l[2] * a2);
+    p.px = (float)((lx[0] * a0 + lx[1] * a1) + lx[2] * a2);
+    p.py = (float)((ly[0] * a0 + ly[1] * a1) + ly[2] * a2);
+    return p;
+}
+static inline float plane_at(const orc_plane* p, float dx, float dy) { return fmaf(p->py, dy, fmaf(p->px, dx, p->p0)); }
+
+/* s0, s1, s2 in clockwise order, area2 = twice the (positive) area in 24.8 x 24.8 units */
+static void planes_setup(orc_planes* P, const orc_sv* s0, const orc_sv* s1, const orc_sv* s2, int64_t area2, int ax, int ay)
+{
+    P->ax = ax; P->ay = ay;
+    const double inv = 1.0 / (double)area2;
+    const int64_t PX = (int64_t)ax * 256 + 128, PY = (int64_t)ay * 256 + 128;
+    /* barycentrics of the anchor's centre and their steps per pixel: l1 = E(s2,s0) / area2, l2 = E(s0,s1) / area2 */
+    double l[3], lx[3], ly[3];
+    l[1] = (double)edge_fn(s2, s0, PX, PY) * inv; l[2] = (double)edge_fn(s0, s1, PX, PY) * inv; l[0] = (1.0 - l[1]) - l[2];
+    lx[1] = (double)(-(int64_t)(s0->Y - s2->Y) * 256) * inv; lx[2] = (double)(-(int64_t)(s1->Y - s0->Y) * 256) * inv; lx[0] = (0.0 - lx[1]) - lx[2];
+    ly[1] = (double)((int64_t)(s0->X - s2->X) * 256) * inv;  ly[2] = (double)((int64_t)(s1->X - s0->X) * 256) * inv;  ly[0] = (0.0 - ly[1]) - ly[2];
+    P->z = plane_of(l, lx, ly, (double)s0->z, (double)s1->z, (double)s2->z);
+    P->q = plane_of(l, lx, ly, (double)s0->iw, (double)s1->iw, (double)s2->iw);
+    P->nx = plane_of(l, lx, ly, (double)s0->wx * (double)s0->iw, (double)s1->wx * (double)s1->iw, (double)s2->wx * (double)s2->iw);
+    P->nz = plane_of(l, lx, ly, (double)s0->wz * (double)s0->iw, (double)s1->wz * (double)s1->iw, (double)s2->wz * (double)s2->iw);
+}
+
+typedef struct { float wx, wz, dwxdx, dwzdx, dwxdy, dwzdy; } orc_attr;
+static orc_attr interp(const orc_planes* P, float dx, float dy)
+{
+    float q = plane_at(&P->q, dx, dy);
+    float r = 1.0f / q;
     orc_attr a;
-    a.wx = (b0 * v0->wx + b1 * v1->wx) + b2 * v2->wx;
-    a.wz = (b0 * v0->wz + b1 * v1->wz) + b2 * v2->wz;
-    for (int dir = 0; dir < 2; dir++) {
-        float dl1 = (float)(dir ? dE1dy : dE1dx) * inv_area, dl2 = (float)(dir ? dE2dy : dE2dx) * inv_area;
-        float dl0 = (0.0f - dl1) - dl2;
-        float dq0 = dl0 * v0->iw, dq1 = dl1 * v1->iw, dq2 = dl2 * v2->iw;
-        float dden = (dq0 + dq1) + dq2;
-        float nx = (dq0 * v0->wx + dq1 * v1->wx) + dq2 * v2->wx;
-        float nz = (dq0 * v0->wz + dq1 * v1->wz) + dq2 * v2->wz;
-        float dx = (nx - a.wx * dden) * r, dz = (nz - a.wz * dden) * r;
-        if (dir) { a.dwxdy = dx; a.dwzdy = dz; } else { a.dwxdx = dx; a.dwzdx = dz; }
-    }
+    a.wx = plane_at(&P->nx, dx, dy) * r;
+    a.wz = plane_at(&P->nz, dx, dy) * r;
+    a.dwxdx = fmaf(-a.wx, P->q.px, P->nx.px) * r; a.dwzdx = fmaf(-a.wz, P->q.px, P->nz.px) * r;
+    a.dwxdy = fmaf(-a.wx, P->q.py, P->nx.py) * r; a.dwzdy = fmaf(-a.wz, P->q.py, P->nz.py) * r;
     return a;
 }
 
@@ -821,7 +859,7 @@ static void pixel_shader(const orc_terrain* t, orc_attr p,
     tex_trilinear(&t->height, lod_h, u + 0.0f, v + (-offset), b);
     float hDy = a[0] - b[0];                                                           /* :61 */
     float n[3] = { -hDx, 2.0f * offset, -hDy };                                        /* :63 */
-    float inv = 1.0f / sqrtf(dot3(n, n));
+    float inv = 1.0f / sqrtf(fmaf(n[2], n[2], fmaf(n[0], n[0], n[1] * n[1])));         /* normalize(): x / length(x) */
     n[0] *= inv; n[1] *= inv; n[2] *= inv;
     float col[3];
     tex_trilinear(&t->albedo, lod_c, u, v, col);                                       /* :68 */
@@ -841,28 +879,25 @@ static inline int owns_pixel(const vr_partition* part, int x, int y)
 }
 
 /* One covered pixel of a triangle: depth from the triangle's plane at the pixel centre, depth clip,
- * LessOrEqual test (in draw order), then main_ps.  E1 / E2 are the unbiased edge functions. */
+ * LessOrEqual test (in draw order), then main_ps. */
 typedef struct {
     const orc_terrain* t; orc_target* tg;
     const orc_sv *s0, *s1, *s2;
-    float inv_area, dz1, dz2;
+    orc_planes P;
 } orc_frag_ctx;
 
-static void fragment(const orc_frag_ctx* f, int x, int y, int64_t E1, int64_t E2)
+static void fragment(const orc_frag_ctx* f, int x, int y)
 {
     orc_target* tg = f->tg;
     if (!owns_pixel(tg->part, x, y)) return;
-    float l1 = (float)E1 * f->inv_area, l2 = (float)E2 * f->inv_area;
-    float z = (f->s0->z + l1 * f->dz1) + l2 * f->dz2;
+    const float dx = (float)(x - f->P.ax), dy = (float)(y - f->P.ay);
+    float z = plane_at(&f->P.z, dx, dy);
     if (!(z >= 0.0f && z <= 1.0f)) return;                    /* depth clip */
     size_t idx = (size_t)y * tg->w + x;
     if (!(z <= tg->depth[idx])) return;                       /* ComparisonFunc::LessOrEqual (TerrainPass.cpp:482) */
     tg->depth[idx] = z + 0.0f;
     if (tg->depth_only) return;
-    /* per-pixel steps of E1 = edge(s2,s0) and E2 = edge(s0,s1) */
-    orc_attr p = interp(f->s0, f->s1, f->s2, f->inv_area, E1, E2,
-                        -(int64_t)(f->s0->Y - f->s2->Y) * 256, -(int64_t)(f->s1->Y - f->s0->Y) * 256,
-                        (int64_t)(f->s0->X - f->s2->X) * 256, (int64_t)(f->s1->X - f->s0->X) * 256);
+    orc_attr p = interp(&f->P, dx, dy);
     pixel_shader(f->t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
 }
 
@@ -893,8 +928,7 @@ static void wire_edge(const orc_frag_ctx* f, const orc_sv* a, const orc_sv* b, i
             int64_t PX = (int64_t)px * 256 + 128;
             int64_t py = floor_div((int64_t)a->Y * dX + (PX - a->X) * dY, dX * 256);
             if (py < vy0 || py > vy1) continue;
-            int64_t PY = py * 256 + 128;
-            fragment(f, px, (int)py, edge_fn(f->s2, f->s0, PX, PY), edge_fn(f->s0, f->s1, PX, PY));
+            fragment(f, px, (int)py);
         }
     } else {
         int32_t lo = a->Y < b->Y ? a->Y : b->Y, hi = a->Y < b->Y ? b->Y : a->Y;
@@ -905,8 +939,7 @@ static void wire_edge(const orc_frag_ctx* f, const orc_sv* a, const orc_sv* b, i
             int64_t PY = (int64_t)py * 256 + 128;
             int64_t px = floor_div((int64_t)a->X * dY + (PY - a->Y) * dX, dY * 256);
             if (px < vx0 || px > vx1) continue;
-            int64_t PX = px * 256 + 128;
-            fragment(f, (int)px, py, edge_fn(f->s2, f->s0, PX, PY), edge_fn(f->s0, f->s1, PX, PY));
+            fragment(f, (int)px, py);
         }
     }
 }
@@ -932,11 +965,19 @@ static void raster_triangle(const orc_terrain* t, const vr_view* view, orc_targe
     if (vy1 > tg->h - 1) vy1 = tg->h - 1;
     if (vx0 < 0) vx0 = 0;
     if (vy0 < 0) vy0 = 0;
-    orc_frag_ctx fc = { t, tg, &s0, &s1, &s2, 1.0f / (float)area2, s1.z - s0.z, s2.z - s0.z };
+    orc_frag_ctx fc = { t, tg, &s0, &s1, &s2, { 0 } };
     if (tg->wireframe) {
         /* RasterFillMode::Wireframe (TerrainPass.cpp:476): the three edges of every triangle that
          * survives culling, as aliased lines; each line pixel is shaded as a sample of the
-         * triangle's plane at that pixel centre. */
+         * triangle's plane at that pixel centre.  A line pixel is the one that contains the line
+         * point: the box of candidate pixels (and the planes' anchor) is floor(min) .. floor(max). */
+        int wx0 = minX >> 8, wy0 = minY >> 8, wx1 = maxX >> 8, wy1 = maxY >> 8;
+        if (wx0 < vx0) wx0 = vx0;
+        if (wy0 < vy0) wy0 = vy0;
+        if (wx1 > vx1) wx1 = vx1;
+        if (wy1 > vy1) wy1 = vy1;
+        if (wx0 > wx1 || wy0 > wy1) return;
+        planes_setup(&fc.P, &s0, &s1, &s2, area2, wx0, wy0);
         wire_edge(&fc, &s0, &s1, vx0, vy0, vx1, vy1);
         wire_edge(&fc, &s1, &s2, vx0, vy0, vx1, vy1);
         wire_edge(&fc, &s2, &s0, vx0, vy0, vx1, vy1);
@@ -950,12 +991,13 @@ static void raster_triangle(const orc_terrain* t, const vr_view* view, orc_targe
     if (x1 > vx1) x1 = vx1;
     if (y1 > vy1) y1 = vy1;
     if (x0 > x1 || y0 > y1) return;
+    planes_setup(&fc.P, &s0, &s1, &s2, area2, x0, y0);
     int b0 = top_left(&s1, &s2) ? 0 : 1, b1 = top_left(&s2, &s0) ? 0 : 1, b2 = top_left(&s0, &s1) ? 0 : 1;
     for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) {
         int64_t PX = (int64_t)x * 256 + 128, PY = (int64_t)y * 256 + 128;
         int64_t E0 = edge_fn(&s1, &s2, PX, PY), E1 = edge_fn(&s2, &s0, PX, PY), E2 = edge_fn(&s0, &s1, PX, PY);
         if (E0 - b0 < 0 || E1 - b1 < 0 || E2 - b2 < 0) continue;
-        fragment(&fc, x, y, E1, E2);
+        fragment(&fc, x, y);
     }
 }
 

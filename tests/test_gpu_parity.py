@@ -69,6 +69,67 @@ def test_select_node_ids_and_instances_bit_exact(scene_name, request, oracle):
             assert np.array_equal(inst_g, inst_o), cam
 
 
+def test_vertex_stage_bit_exact(scene2048, oracle, gpu_ctx):
+    """main_vs on its own (terrain_vs.hlsl:10-25, :35-62): o_position and the world xz of every one of the 1,089 grid
+    vertices of chosen instances - the nearest node, one whose vertices lie in the morph band (0 < morphK < 1), the
+    coarsest, and the last of the draw - bit for bit against the oracle's vertex_shader, not through rasterised depth."""
+    ot, tp = scene2048["ot"], scene2048["tp"]
+    eye, tgt = CAMERAS[0]
+    w, h = 960, 540
+    v = vr.make_view(eye, tgt, w, h)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    tp.Render(v, v, rt, vr.default_render_params(400.0))
+    n, ids, inst = ot.select(v, 400.0)
+    assert tp.num_chunks() == n and n > 8
+    ext = inst.view(np.float32)[:, 4]                       # transform[0] = the node's half-extent
+    pos = inst.view(np.float32)[:, [7, 15]]                 # transform[3], transform[11] = position x, z
+    dist = np.hypot(pos[:, 0] - eye[0], pos[:, 1] - eye[2])
+    ranges = ot.lod_ranges()
+    # a node that straddles its LOD range's morph start (0.85 r): some of its vertices morph partially
+    lod = np.clip(np.floor(np.log2(2.0 * ext)).astype(int), 0, 11)
+    band = np.abs(dist - 0.925 * ranges[lod]) - ext
+    chosen = sorted({int(np.argmin(dist)), int(np.argmin(band)), int(np.argmax(ext)), n - 1, 0})
+    partial = 0
+    for i in chosen:
+        got = tp.download_vertices(i, 1)[0]
+        want = np.empty((1089, 6), np.float32)
+        for vz in range(33):
+            for vx in range(33):
+                clip, world = ot.vertex(v, 400.0, inst[i], vx, vz)
+                want[vz * 33 + vx, :4] = clip
+                want[vz * 33 + vx, 4] = world[0]; want[vz * 33 + vx, 5] = world[2]
+        mis = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        assert mis.size == 0, f"instance {i} (node {ids[i]}): {len(mis)} vertex components differ, first {mis[:4].tolist()}"
+        # odd grid vertices move when morphK > 0: count vertices strictly between the two mesh resolutions
+        base = pos[i, 0] + ext[i] * ((np.arange(33) - 16) / 16.0)
+        moved = np.abs(got[:33, 4] - base.astype(np.float32))
+        step = 2.0 * ext[i] / 32.0
+        partial += int(np.sum((moved > 1e-6 * step) & (moved < step * (1.0 - 1e-6))))
+    assert partial > 0, "no chosen instance had a partially morphed vertex - the morph band was not exercised"
+    rt.close()
+
+
+def test_config2_1080p_single_surface_at_its_own_size(scene256, oracle, gpu_ctx):
+    """BASELINE config 2 at its own size: 1920x1080, the 256^2 single-surface scene, the reference camera
+    (Renderer.cpp:97,315) scaled to the surface, 1 directional light: G-buffer bit-exact, HdrColor RMS <= 1e-4."""
+    eye, tgt = scaled_camera(CAMERAS[0], 256)
+    w, h = 1920, 1080
+    v, gb_o, planes, n_o, n_g = _render_both(scene256, oracle, gpu_ctx, eye, tgt, w, h, assume_cleared=1)
+    assert n_o == n_g
+    _assert_gbuffer_equal(gb_o, planes, "config 2, 1920x1080")
+    assert (gb_o.depth < 1.0).mean() > 0.3
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    tp = scene256["tp"]
+    tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1))
+    hdr = vr.HdrImage(gpu_ctx, w, h)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+    got = oracle.half_to_float(hdr.download()).astype(np.float64)
+    want = oracle.half_to_float(oracle.deferred(v, gb_o, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)).astype(np.float64)
+    rms = np.sqrt(np.mean((got - want) ** 2, axis=(0, 1)))
+    assert (rms <= 1e-4).all(), f"per-channel HDR RMS {rms} exceeds 1e-4"
+    hdr.close(); rt.close()
+
+
 def _render_both(sc, oracle, gpu_ctx, eye, tgt, w, h, assume_cleared=0, depth_only=0, part=None, wireframe=0):
     ot, tp = sc["ot"], sc["tp"]
     v = vr.make_view(eye, tgt, w, h)

@@ -11,6 +11,7 @@
 
 #include <dlfcn.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 // rccl.h: ncclDataType_t / ncclRedOp_t values used here
@@ -19,18 +20,20 @@ typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*ErrStrFn)(int);
 
+// Resolved exactly once (std::call_once): a host may drive its ranks as threads of one process (tests/host/
+// frame_allgather_example.cpp), and every one of them comes through rccl_load() on its first frame.  The pointers are
+// written inside the once-block only and read after it has returned, so no thread can see a half-filled table.
 struct Rccl {
-    bool tried = false;
+    std::once_flag once;
     AllGatherFn all_gather = nullptr;
     AllReduceFn all_reduce = nullptr;
     ErrStrFn err_str = nullptr;
-    std::string where;
 };
 Rccl g_rccl;
 
-void* find_symbol(const char* name, std::string* where)
+void* find_symbol(const char* name)
 {
-    if (void* p = dlsym(RTLD_DEFAULT, name)) { *where = "global scope"; return p; }
+    if (void* p = dlsym(RTLD_DEFAULT, name)) return p;
     const char* env = getenv("VRTERRAIN_RCCL");
     const char* names[] = { env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     for (int pass = 0; pass < 2; pass++)                       // first a copy that is already loaded, then a fresh load
@@ -38,19 +41,18 @@ void* find_symbol(const char* name, std::string* where)
             if (!n || !*n) continue;
             void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (!h) continue;
-            if (void* p = dlsym(h, name)) { *where = n; return p; }
+            if (void* p = dlsym(h, name)) return p;
         }
     return nullptr;
 }
 
 int rccl_load()
 {
-    if (!g_rccl.tried) {
-        g_rccl.tried = true;
-        g_rccl.all_gather = (AllGatherFn)find_symbol("ncclAllGather", &g_rccl.where);
-        g_rccl.all_reduce = (AllReduceFn)find_symbol("ncclAllReduce", &g_rccl.where);
-        g_rccl.err_str = (ErrStrFn)find_symbol("ncclGetErrorString", &g_rccl.where);
-    }
+    std::call_once(g_rccl.once, [] {
+        g_rccl.all_gather = (AllGatherFn)find_symbol("ncclAllGather");
+        g_rccl.all_reduce = (AllReduceFn)find_symbol("ncclAllReduce");
+        g_rccl.err_str = (ErrStrFn)find_symbol("ncclGetErrorString");
+    });
     if (!g_rccl.all_gather || !g_rccl.all_reduce) {
         vr_set_error("RCCL not found: ncclAllGather / ncclAllReduce are neither in the process nor in librccl.so (set VRTERRAIN_RCCL to its path)");
         return VR_ERR_INVALID_ARGUMENT;

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 // ---- errors ---------------------------------------------------------------------
 static thread_local char g_last_error[512] = "";

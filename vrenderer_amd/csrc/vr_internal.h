@@ -28,6 +28,7 @@ constexpr int kGrid = 32;                    // GRID_SIZE (TerrainPass.h:28)
 constexpr int kSide = kGrid + 1;             // 33 vertices per side
 constexpr int kVertsPerInst = kSide * kSide; // 1089
 constexpr int kTrisPerInst = kGrid * kGrid * 2; // 2048
+constexpr int kRecGroups = 8;                // 16-byte groups per triangle record (vr_raster.hip: write_tri_rec)
 constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of large frames; also the upper bound of either size
 // Tile edge of the raster / bin grid for a w x h target: 64, or 32 when 64-pixel tiles would leave the chip's
 // 1024 workgroup slots short of work (measured in round 2, 64- vs 32-pixel tiles: 1080p tile pass 144 vs 91 us, 1440p 152 vs
@@ -187,7 +188,7 @@ struct GeoSet {
     uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled
-    uint4* d_recs = nullptr;             // per surviving triangle: its set-up record (9 x 16 B), then the clipper's (hard_cap * 4)
+    uint4* d_recs = nullptr;             // per surviving triangle: its set-up record (kRecGroups x 16 B), then the clipper's (hard_cap * 4)
     uint32_t* d_hard_list = nullptr;     // triangle ids that need the clipper
     HardTriRec* d_hard_tris = nullptr;   // capacity hard_cap * 4
     uint32_t* d_hard_first = nullptr;    // per regular triangle id: first HardTriRec index
@@ -200,6 +201,12 @@ struct GeoSet {
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
     hipEvent_t raster_done = nullptr;    // what the geometry stream waits on before reusing this set: ev_raster_done, or the tile pass's own stop event
     bool raster_recorded = false, have_selection = false;
+    // Successive chains on one set may run on different geometry streams (they take turns) and a chain is not always
+    // consumed by a tile pass (an evicted prepared set, vr_terrain_select alone): every writer of the set first waits for
+    // the set's previous chain (ev_geo_done) and for a lock_view copy that may still be reading its selection.
+    bool geo_recorded = false;           // ev_geo_done has been recorded at least once
+    hipEvent_t ev_sel_read = nullptr;    // recorded behind a lock_view copy OUT of this set (on the copying set's stream)
+    bool sel_read_pending = false;
     // The geometry stream this set's last chain ran on (the terrain's two streams take turns, so that two prepared
     // frames have their latency-bound chains in flight at once).
     hipStream_t stream = nullptr;

@@ -61,7 +61,7 @@ enum { C_COUNT = 0, C_FLAGS = 1, C_HARDTRIS = 2, C_XVERTS = 3, C_HARDLIST = 4, C
 struct QuadTap { uint32_t idx; float fx, fy; };
 __device__ __forceinline__ QuadTap quad_tap(int w, int h, float u, float v)
 {
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x = __builtin_fmaf(u, (float)w, -0.5f), y = __builtin_fmaf(v, (float)h, -0.5f);
     float xf = floorf(x), yf = floorf(y);
     QuadTap q; q.fx = x - xf; q.fy = y - yf;
     xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
@@ -71,8 +71,8 @@ __device__ __forceinline__ QuadTap quad_tap(int w, int h, float u, float v)
 __device__ __forceinline__ float quad_filter(uint32_t e, const QuadTap& q, const float* __restrict__ r8)
 {
     const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
-    const float top = t00 + (t10 - t00) * q.fx, bot = t01 + (t11 - t01) * q.fx;
-    return top + (bot - top) * q.fy;
+    const float top = __builtin_fmaf(t10 - t00, q.fx, t00), bot = __builtin_fmaf(t11 - t01, q.fx, t01);   // the sampler's lerps are fused (oracle: tex_bilinear)
+    return __builtin_fmaf(bot - top, q.fy, top);
 }
 // ---------------------------------------------------------------------------------------
 // vertex stage (terrain_vs.hlsl:35-62)
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
             const QuadTap t0 = quad_tap(w0, h0, u, w_), t1 = quad_tap(w1, h1, u, w_);
             const uint32_t e0 = hm.quad[s_qoff[ls.l0] + t0.idx], e1 = hm.quad[s_qoff[l1] + t1.idx];
             const float s0 = quad_filter(e0, t0, r8), s1 = quad_filter(e1, t1, r8);
-            const float hv = ls.f > 0.0f ? s0 + (s1 - s0) * ls.f : s0;
+            const float hv = ls.f > 0.0f ? __builtin_fmaf(s1 - s0, ls.f, s0) : s0;
             world[1] = hv * a.max_height;                                                           // :51
         }
         float viewPos[4], clip[4];
@@ -184,8 +184,8 @@ struct TriSetup {
     int32_t A0, B0, A1, B1, A2, B2;   // E_i(PX,PY) = A_i*PX + B_i*PY + C_i
     int64_t C0, C1, C2;
     int32_t bias0, bias1, bias2;      // 0 for top-left edges, else 1
-    float z0, dz1, dz2, inv_area;
-    int x0, y0, x1, y1;               // inclusive pixel bounds after clamping
+    int64_t area2;                    // twice the area, 24.8 x 24.8 units, > 0 (clockwise)
+    int x0, y0, x1, y1;               // inclusive pixel bounds after clamping; (x0, y0) is the anchor of the planes
     bool visible;
 };
 
@@ -222,8 +222,7 @@ __device__ __forceinline__ TriSetup tri_setup(ScreenVert& s0, ScreenVert& s1, Sc
     t.bias0 = is_top_left(s2.X - s1.X, s2.Y - s1.Y) ? 0 : 1;
     t.bias1 = is_top_left(s0.X - s2.X, s0.Y - s2.Y) ? 0 : 1;
     t.bias2 = is_top_left(s1.X - s0.X, s1.Y - s0.Y) ? 0 : 1;
-    t.inv_area = 1.0f / (float)area2;
-    t.z0 = s0.z; t.dz1 = s1.z - s0.z; t.dz2 = s2.z - s0.z;
+    t.area2 = area2;
     t.visible = true;
     return t;
 }
@@ -240,78 +239,67 @@ __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1
     return (uint64_t)(uint32_t)tx0 | ((uint64_t)(uint32_t)ty0 << 16) | ((uint64_t)(uint32_t)tx1 << 32) | ((uint64_t)(uint32_t)ty1 << 48);
 }
 
-// Perspective-correct world xz at a pixel centre and its screen-space derivatives (analytic
-// derivative of the same interpolant; feeds the implicit LOD of Texture2D::Sample).
-struct TriDeriv { float dl1dx, dl2dx, dl1dy, dl2dy; };      // per-pixel steps of the barycentrics
-
-__device__ __forceinline__ TriDeriv tri_derivs(const TriSetup& t)
+// Fixed-function interpolation as per-triangle plane equations (oracle: planes_setup, raster model revision 3): depth z,
+// q = 1/w and the attributes over w are affine in the pixel position, P(x, y) = p0 + px (x - ax) + py (y - ay) about the
+// anchor pixel (ax, ay) = the first pixel of the triangle's viewport-clamped box.  The coefficients are set up once per
+// triangle in double precision from the exact integer edge functions - the same expressions, in the same order, as the
+// oracle - and rounded to float; a pixel evaluates fma(py, dy, fma(px, dx, p0)).
+struct Plane { float p0, px, py; };
+__device__ __forceinline__ Plane plane_of(const double l[3], const double lx[3], const double ly[3], double a0, double a1, double a2)
 {
-    // (float)(A * 256) == (float)A * 256 exactly (power-of-two scaling)
-    TriDeriv d;
-    d.dl1dx = ((float)t.A1 * 256.0f) * t.inv_area; d.dl2dx = ((float)t.A2 * 256.0f) * t.inv_area;
-    d.dl1dy = ((float)t.B1 * 256.0f) * t.inv_area; d.dl2dy = ((float)t.B2 * 256.0f) * t.inv_area;
-    return d;
+    Plane p;
+    p.p0 = (float)((l[0] * a0 + l[1] * a1) + l[2] * a2);
+    p.px = (float)((lx[0] * a0 + lx[1] * a1) + lx[2] * a2);
+    p.py = (float)((ly[0] * a0 + ly[1] * a1) + ly[2] * a2);
+    return p;
 }
+__device__ __forceinline__ float plane_at(float p0, float px, float py, float dx, float dy) { return __builtin_fmaf(py, dy, __builtin_fmaf(px, dx, p0)); }
 
 // Triangle record: everything the tile pass needs of a triangle that survived culling, written once by
 // k_setup (regular triangles, index = triangle id) or k_clip (clipper output, index = kRecHardBase-relative)
-// and read by both phases of k_raster, so neither re-derives the set-up from the vertices.  Nine 16-byte
-// groups (144 B):
+// and read by both phases of k_raster, so neither re-derives the set-up from the vertices.  Eight 16-byte
+// groups (128 B):
 //   0: A0 B0 C0(lo hi)        edge 0            (coverage)
-//   1: A1 B1 C1(lo hi)        edge 1            (coverage + barycentric l1)
-//   2: A2 B2 C2(lo hi)        edge 2            (coverage + barycentric l2)
-//   3: z0 dz1 dz2 inv_area    depth plane       (coverage)
-//   4: box0 box1 flags -      pixel box (x | y << 16, inclusive, clamped to the viewport); flags: bias0..2, bit 3 = small
-//   5: iw0 iw1 iw2 ddenx      1/w per vertex;   the per-triangle terms of the interpolant's screen-space
-//   6: wx0 wx1 wx2 ddeny      world x           derivative (what interp_attr computed per pixel from constants)
-//   7: wz0 wz1 wz2 inv_area   world z
-//   8: nxx nzx nxy nzy
-//   9..11: edges 1 and 2 once more as doubles - 256*A1, 256*B1, C1, 256*A2, 256*B2, C2 - for the resolve, which evaluates
-//          them in fp64 (exact: integers below 2^52) straight from the record, with no integer -> float conversion on the
-//          way; C = NaN marks a giant (|A| or |B| >= 2^23, clipped at the guard band) that must take the int64 path
+//   1: A1 B1 C1(lo hi)        edge 1            (coverage)
+//   2: A2 B2 C2(lo hi)        edge 2            (coverage)
+//   3: Z0 Zx Zy flags         depth plane       (coverage); flags: bias0..2, bit 3 = small
+//   4: box0 box1 - -          pixel box (x | y << 16, inclusive, clamped to the viewport); box0 is the planes' anchor
+//   5: Q0 Qx Qy box0          1/w plane + anchor        (resolve)
+//   6: NX0 NXx NXy -          (world x) / w plane       (resolve)
+//   7: NZ0 NZx NZy -          (world z) / w plane       (resolve)
 // small = every |A_i|, |B_i| <= 2^14 (edges up to 64 pixels): every edge value at a pixel of a tile the triangle
 // touches then fits 31 bits (|E(P)| <= 2^29 inside its box, + 64 pixels * 256 * (|A|+|B|) <= 2^29 to any pixel of
 // the tile), and 256*B fits 24 bits, so the tile pass runs such triangles in int32 / mad24.
-constexpr int kRecGroups = 12;
 constexpr int32_t kSmallEdge = 1 << 14;
 
 __device__ __forceinline__ void write_tri_rec(uint4* __restrict__ dst, const TriSetup& t, const ScreenVert& s0, const ScreenVert& s1,
                                               const ScreenVert& s2)
 {
-    const TriDeriv td = tri_derivs(t);
-    float ddenx, nxx, nzx, ddeny, nxy, nzy;
-    {
-        const float dl1 = td.dl1dx, dl2 = td.dl2dx, dl0 = (0.0f - dl1) - dl2;
-        const float dq0 = dl0 * s0.iw, dq1 = dl1 * s1.iw, dq2 = dl2 * s2.iw;
-        ddenx = (dq0 + dq1) + dq2;
-        nxx = (dq0 * s0.wx + dq1 * s1.wx) + dq2 * s2.wx; nzx = (dq0 * s0.wz + dq1 * s1.wz) + dq2 * s2.wz;
-    }
-    {
-        const float dl1 = td.dl1dy, dl2 = td.dl2dy, dl0 = (0.0f - dl1) - dl2;
-        const float dq0 = dl0 * s0.iw, dq1 = dl1 * s1.iw, dq2 = dl2 * s2.iw;
-        ddeny = (dq0 + dq1) + dq2;
-        nxy = (dq0 * s0.wx + dq1 * s1.wx) + dq2 * s2.wx; nzy = (dq0 * s0.wz + dq1 * s1.wz) + dq2 * s2.wz;
-    }
+    // barycentrics of the anchor's centre and their steps per pixel: l1 = E1 / area2, l2 = E2 / area2 (E1 = edge(s2, s0), E2 = edge(s0, s1))
+    const double inv = 1.0 / (double)t.area2;
+    const int64_t PX = (int64_t)t.x0 * 256 + 128, PY = (int64_t)t.y0 * 256 + 128;
+    const int64_t E1 = (int64_t)t.A1 * PX + ((int64_t)t.B1 * PY + t.C1), E2 = (int64_t)t.A2 * PX + ((int64_t)t.B2 * PY + t.C2);
+    double l[3], lx[3], ly[3];
+    l[1] = (double)E1 * inv; l[2] = (double)E2 * inv; l[0] = (1.0 - l[1]) - l[2];
+    lx[1] = (double)((int64_t)t.A1 * 256) * inv; lx[2] = (double)((int64_t)t.A2 * 256) * inv; lx[0] = (0.0 - lx[1]) - lx[2];
+    ly[1] = (double)((int64_t)t.B1 * 256) * inv; ly[2] = (double)((int64_t)t.B2 * 256) * inv; ly[0] = (0.0 - ly[1]) - ly[2];
+    const Plane z = plane_of(l, lx, ly, (double)s0.z, (double)s1.z, (double)s2.z);
+    const Plane q = plane_of(l, lx, ly, (double)s0.iw, (double)s1.iw, (double)s2.iw);
+    const Plane nx = plane_of(l, lx, ly, (double)s0.wx * (double)s0.iw, (double)s1.wx * (double)s1.iw, (double)s2.wx * (double)s2.iw);
+    const Plane nz = plane_of(l, lx, ly, (double)s0.wz * (double)s0.iw, (double)s1.wz * (double)s1.iw, (double)s2.wz * (double)s2.iw);
     const int32_t m = max(max(max(abs(t.A0), abs(t.B0)), max(abs(t.A1), abs(t.B1))), max(abs(t.A2), abs(t.B2)));
     const uint32_t flags = (uint32_t)t.bias0 | ((uint32_t)t.bias1 << 1) | ((uint32_t)t.bias2 << 2) | (m <= kSmallEdge ? 8u : 0u);
+    const uint32_t box0 = (uint32_t)t.x0 | ((uint32_t)t.y0 << 16), box1 = (uint32_t)t.x1 | ((uint32_t)t.y1 << 16);
 #define F2U(x) __float_as_uint(x)
     dst[0] = make_uint4((uint32_t)t.A0, (uint32_t)t.B0, (uint32_t)(uint64_t)t.C0, (uint32_t)((uint64_t)t.C0 >> 32));
     dst[1] = make_uint4((uint32_t)t.A1, (uint32_t)t.B1, (uint32_t)(uint64_t)t.C1, (uint32_t)((uint64_t)t.C1 >> 32));
     dst[2] = make_uint4((uint32_t)t.A2, (uint32_t)t.B2, (uint32_t)(uint64_t)t.C2, (uint32_t)((uint64_t)t.C2 >> 32));
-    dst[3] = make_uint4(F2U(t.z0), F2U(t.dz1), F2U(t.dz2), F2U(t.inv_area));
-    dst[4] = make_uint4((uint32_t)t.x0 | ((uint32_t)t.y0 << 16), (uint32_t)t.x1 | ((uint32_t)t.y1 << 16), flags, 0u);
-    dst[5] = make_uint4(F2U(s0.iw), F2U(s1.iw), F2U(s2.iw), F2U(ddenx));
-    dst[6] = make_uint4(F2U(s0.wx), F2U(s1.wx), F2U(s2.wx), F2U(ddeny));
-    dst[7] = make_uint4(F2U(s0.wz), F2U(s1.wz), F2U(s2.wz), F2U(t.inv_area));
-    dst[8] = make_uint4(F2U(nxx), F2U(nzx), F2U(nxy), F2U(nzy));
+    dst[3] = make_uint4(F2U(z.p0), F2U(z.px), F2U(z.py), flags);
+    dst[4] = make_uint4(box0, box1, 0u, 0u);
+    dst[5] = make_uint4(F2U(q.p0), F2U(q.px), F2U(q.py), box0);
+    dst[6] = make_uint4(F2U(nx.p0), F2U(nx.px), F2U(nx.py), 0u);
+    dst[7] = make_uint4(F2U(nz.p0), F2U(nz.px), F2U(nz.py), 0u);
 #undef F2U
-    {
-        const bool dok = max(max(abs(t.A1), abs(t.B1)), max(abs(t.A2), abs(t.B2))) < (1 << 23);
-        const double nan = __longlong_as_double(0x7ff8000000000000ll);
-        double* d = reinterpret_cast<double*>(dst + 9);
-        d[0] = (double)t.A1 * 256.0; d[1] = (double)t.B1 * 256.0; d[2] = dok ? (double)t.C1 : nan;
-        d[3] = (double)t.A2 * 256.0; d[4] = (double)t.B2 * 256.0; d[5] = dok ? (double)t.C2 : nan;
-    }
 }
 
 // Sets a triangle up against the viewport: its raster-tile rectangle, or ~0 when it is culled; a surviving
@@ -623,11 +611,11 @@ __device__ __forceinline__ float div_ws(const RasterArgs& a, float s)
 __device__ __forceinline__ float to_uv(const RasterArgs& a, float x) { return div_ws(a, x + a.world_size * 0.5f); }
 
 // One axis of a bilinear footprint: texel-space coordinate -> integer floor (clamped to [-1, n], as the quad table is
-// indexed) and fraction.  Same operations as quad_tap / vr_bilinear_setup, once per distinct coordinate.
+// indexed) and fraction.  Same operations as quad_tap / the oracle's tex_bilinear (u * n - 0.5 fused), once per distinct coordinate.
 struct Axis { int i; float f; };
 __device__ __forceinline__ Axis tap_axis(int n, float t)
 {
-    const float x = t * (float)n - 0.5f;
+    const float x = __builtin_fmaf(t, (float)n, -0.5f);
     float xf = floorf(x);
     Axis r; r.f = x - xf;
     r.i = (int)vr_clampf(xf, -1.0f, (float)n);
@@ -671,16 +659,17 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     }
 #undef LDQ
 #undef LDC
-    // entry = (t00, t10 - t00, t01, t11 - t01): top = t00 + (t10 - t00) * fx, bot likewise, then across y
-#define QF(e, fx, fy) ({ const float top_ = __uint_as_float((e).x) + __uint_as_float((e).y) * (fx), bot_ = __uint_as_float((e).z) + __uint_as_float((e).w) * (fx); \
-                         top_ + (bot_ - top_) * (fy); })
+    // entry = (t00, t10 - t00, t01, t11 - t01): top = fma(t10 - t00, fx, t00), bot likewise, then across y (fused lerps, oracle: tex_bilinear)
+#define QF(e, fx, fy) ({ const float top_ = __builtin_fmaf(__uint_as_float((e).y), (fx), __uint_as_float((e).x)), \
+                                     bot_ = __builtin_fmaf(__uint_as_float((e).w), (fx), __uint_as_float((e).z)); \
+                         __builtin_fmaf(bot_ - top_, (fy), top_); })
     hgt[0] = QF(e0, xa.f, y0.f); hgt[1] = QF(e1, xb.f, y0.f); hgt[2] = QF(e2, x0.f, ya.f); hgt[3] = QF(e3, x0.f, yb.f);
 #undef QF
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float t00 = __uint_as_float(p00[k]), t10 = __uint_as_float(p10[k]), t01 = __uint_as_float(p01[k]), t11 = __uint_as_float(p11[k]);
-        const float top = t00 + (t10 - t00) * cfx, bot = t01 + (t11 - t01) * cfx;
-        col[k] = top + (bot - top) * cfy;
+        const float top = __builtin_fmaf(t10 - t00, cfx, t00), bot = __builtin_fmaf(t11 - t01, cfx, t01);
+        col[k] = __builtin_fmaf(bot - top, cfy, top);
     }
 }
 
@@ -703,7 +692,8 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     LodSplit lc = lh;                                            // same size and level count: the same LOD
     if (!SAME) lc = vr_lod_split(al.levels, vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, al.w0, al.h0));
     const float offset = 0.1f;                                                              // :59
-    const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset), u0 = u + 0.0f, v0 = v + 0.0f;
+    // (uv + float2(offset, 0.0)'s "+ 0.0" only turns -0 into +0, which no later operation can tell apart: fma(+-0, n, -0.5) = -0.5)
+    const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset), u0 = u, v0 = v;
     float hgt[4], col[3];
     sample_level<SAME>(hm, al, rq, rc, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
@@ -717,14 +707,16 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
         asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ya), "+v"(yb), "+v"(x0), "+v"(y0), "+v"(xu), "+v"(yv));
         float g[4], cb[3];
         sample_level<SAME>(hm, al, rq, rc, qoff, aoff, l1h, l1c, xa, xb, ya, yb, x0, y0, xu, yv, g, cb);
-        hgt[0] = hgt[0] + (g[0] - hgt[0]) * lh.f; hgt[1] = hgt[1] + (g[1] - hgt[1]) * lh.f;
-        hgt[2] = hgt[2] + (g[2] - hgt[2]) * lh.f; hgt[3] = hgt[3] + (g[3] - hgt[3]) * lh.f;
+        // fma(b - a, f, a): with f == 0 this is a exactly (b - a is finite), as the oracle's "f > 0" branch leaves it
 #pragma unroll
-        for (int k = 0; k < 3; k++) col[k] = col[k] + (cb[k] - col[k]) * lc.f;
+        for (int k = 0; k < 4; k++) hgt[k] = __builtin_fmaf(g[k] - hgt[k], lh.f, hgt[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) col[k] = __builtin_fmaf(cb[k] - col[k], lc.f, col[k]);
     }
     const float hDx = hgt[0] - hgt[1], hDy = hgt[2] - hgt[3];                                // :60-61
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
-    const float inv = vr_rcp_exact(vr_sqrt_exact(vr_dot3(nx, ny, nz, nx, ny, nz)));         // 1.0f / sqrtf(.), length in [0.2, 1.43]
+    // normalize(): 1.0f / sqrtf(fma(nz, nz, fma(nx, nx, ny * ny))), length in [0.2, 1.43]
+    const float inv = vr_rcp_exact(vr_sqrt_exact(__builtin_fmaf(nz, nz, __builtin_fmaf(nx, nx, ny * ny))));
     nx *= inv; ny *= inv; nz *= inv;
     diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
@@ -746,30 +738,35 @@ constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels whe
 constexpr int kRowMin = VR_ROW_MIN;  // the row hand-out needs this many eligible triangles in a wave (its scan + fetches are a fixed cost)
 constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)
 
-// Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
-// of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
-// When every value over the tile fits in 32 bits the sweep runs in int32, else in int64.
-template <typename T, int TILE>
-__device__ __forceinline__ void cover_pixel(unsigned long long* __restrict__ vis, int lx, int ly, T v1, T v2, int b1, int b2,
-                                            float z0, float dz1, float dz2, float ia, uint32_t ord)
+// The depth plane of a triangle as the coverage sweeps carry it: coefficients + the tile's origin relative to the anchor
+// (offx = ox - ax, offy = oy - ay: the plane's dx of tile-local pixel lx is lx + offx, an exact small integer in float).
+struct ZPlane { float z0, zx, zy; int offx, offy; };
+
+// One covered sample: depth from the triangle's plane at the pixel centre (oracle: fragment()), depth clip, LessOrEqual
+// in draw order == 64-bit minimum of (depth bits, ~order).  fx, fy = the pixel's offset from the plane's anchor.
+template <int TILE>
+__device__ __forceinline__ void cover_pixel(unsigned long long* __restrict__ vis, int lx, int ly, float fx, float fy, const ZPlane& zp, uint32_t ord)
 {
-    const float l1 = (float)(v1 + (T)b1) * ia, l2 = (float)(v2 + (T)b2) * ia;
-    float z = (z0 + l1 * dz1) + l2 * dz2;
+    float z = plane_at(zp.z0, zp.zx, zp.zy, fx, fy);
     if (!(z >= 0.0f && z <= 1.0f)) return;                       // depth clip
     z = z + 0.0f;                                                // canonical +0
     atomicMin(&vis[ly * TILE + lx], ((unsigned long long)__float_as_uint(z) << 32) | ord);
 }
 
+// Tile-relative edge functions: E_i(lx, ly) = e_i + sx_i*lx + sy_i*ly for the pixel (lx, ly)
+// of the tile (centre sampled), bias_i = 0 on top-left edges else 1 (inside <=> E_i - bias_i >= 0).
+// When every value over the tile fits in 32 bits the sweep runs in int32, else in int64.
 template <typename T, int TILE>
 __device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
-                                            int b0, int b1, int b2, int x0, int y0, int x1, int y1,
-                                            float z0, float dz1, float dz2, float ia, uint32_t ord)
+                                            int b0, int b1, int b2, int x0, int y0, int x1, int y1, const ZPlane& zp, uint32_t ord)
 {
     for (int y = y0; y <= y1; y++) {
         T r0 = e0 + sy0 * (T)y - (T)b0 + sx0 * (T)x0, r1 = e1 + sy1 * (T)y - (T)b1 + sx1 * (T)x0, r2 = e2 + sy2 * (T)y - (T)b2 + sx2 * (T)x0;
+        const float fy = (float)(y + zp.offy);
+        float fx = (float)(x0 + zp.offx);
         for (int x = x0; x <= x1; x++) {
-            if ((r0 | r1 | r2) >= 0) cover_pixel<T, TILE>(vis, x, y, r1, r2, b1, b2, z0, dz1, dz2, ia, ord);
-            r0 += sx0; r1 += sx1; r2 += sx2;
+            if ((r0 | r1 | r2) >= 0) cover_pixel<TILE>(vis, x, y, fx, fy, zp, ord);
+            r0 += sx0; r1 += sx1; r2 += sx2; fx += 1.0f;
         }
     }
 }
@@ -778,8 +775,7 @@ __device__ __forceinline__ void sweep_small(unsigned long long* __restrict__ vis
 // completely outside an edge are skipped with scalar arithmetic only.
 template <typename T, int TILE>
 __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, int lane, T e0, T e1, T e2, T sx0, T sy0, T sx1, T sy1, T sx2, T sy2,
-                                          int b0, int b1, int b2, int x0, int y0, int x1, int y1,
-                                          float z0, float dz1, float dz2, float ia, uint32_t ord)
+                                          int b0, int b1, int b2, int x0, int y0, int x1, int y1, const ZPlane& zp, uint32_t ord)
 {
     constexpr int BW = kSweepW, BH = 64 / kSweepW;                                                              // block of 64 pixels, one per lane
     const int lx = lane & (BW - 1), ly = lane / BW;
@@ -787,6 +783,7 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
     const T m0 = (sx0 > 0 ? sx0 * (BW - 1) : (T)0) + (sy0 > 0 ? sy0 * (BH - 1) : (T)0);                        // max offset inside a block
     const T m1 = (sx1 > 0 ? sx1 * (BW - 1) : (T)0) + (sy1 > 0 ? sy1 * (BH - 1) : (T)0);
     const T m2 = (sx2 > 0 ? sx2 * (BW - 1) : (T)0) + (sy2 > 0 ? sy2 * (BH - 1) : (T)0);
+    const int lox = lx + zp.offx, loy = ly + zp.offy;
     for (int yb = y0 & ~(BH - 1); yb <= y1; yb += BH) {
         const T r0 = e0 - (T)b0 + sy0 * (T)yb, r1 = e1 - (T)b1 + sy1 * (T)yb, r2 = e2 - (T)b2 + sy2 * (T)yb;
         for (int xb = x0 & ~(BW - 1); xb <= x1; xb += BW) {
@@ -795,7 +792,7 @@ __device__ __forceinline__ void sweep_big(unsigned long long* __restrict__ vis, 
             const T v0 = o0 + l0, v1 = o1 + l1, v2 = o2 + l2;
             const int x = xb + lx, y = yb + ly;
             if ((v0 | v1 | v2) < 0 || x < x0 || x > x1 || y < y0 || y > y1) continue;
-            cover_pixel<T, TILE>(vis, x, y, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
+            cover_pixel<TILE>(vis, x, y, (float)(xb + lox), (float)(yb + loy), zp, ord);
         }
     }
 }
@@ -811,7 +808,7 @@ constexpr int kWalkMin = VR_WALK_MIN;
 template <int TILE>
 __device__ __forceinline__ void sweep_walk(unsigned long long* __restrict__ vis, int lane, int32_t e0, int32_t e1, int32_t e2, int32_t sx0, int32_t sy0,
                                            int32_t sx1, int32_t sy1, int32_t sx2, int32_t sy2, int b0, int b1, int b2, int x0, int y0, int x1, int y1,
-                                           float z0, float dz1, float dz2, float ia, uint32_t ord)
+                                           const ZPlane& zp, uint32_t ord)
 {
     constexpr int PER = 64 / TILE;                               // short-axis positions covered per step: 1, or 2 for 32-pixel tiles
     const bool horiz = (x1 - x0) >= (y1 - y0);                   // (wave-uniform)
@@ -821,9 +818,11 @@ __device__ __forceinline__ void sweep_walk(unsigned long long* __restrict__ vis,
     const int32_t a0 = horiz ? sx0 : sy0, a1 = horiz ? sx1 : sy1, a2 = horiz ? sx2 : sy2;     // step along the long axis
     const int32_t c0 = horiz ? sy0 : sx0, c1 = horiz ? sy1 : sx1, c2 = horiz ? sy2 : sx2;     // step along the short axis
     int32_t v0 = (e0 - b0) + a0 * la + c0 * s0, v1 = (e1 - b1) + a1 * la + c1 * s0, v2 = (e2 - b2) + a2 * la + c2 * s0;
+    const float fla = (float)(la + (horiz ? zp.offx : zp.offy));             // this lane's offset from the anchor along the long axis
+    float fsp = (float)(s0 + (horiz ? zp.offy : zp.offx));                   // ... and along the short one (exact small integers)
     for (int sp = s0; sp <= s1; sp += PER) {
-        if ((v0 | v1 | v2) >= 0) cover_pixel<int32_t, TILE>(vis, horiz ? la : sp, horiz ? sp : la, v1, v2, b1, b2, z0, dz1, dz2, ia, ord);
-        v0 += c0 * PER; v1 += c1 * PER; v2 += c2 * PER;
+        if ((v0 | v1 | v2) >= 0) cover_pixel<TILE>(vis, horiz ? la : sp, horiz ? sp : la, horiz ? fla : fsp, horiz ? fsp : fla, zp, ord);
+        v0 += c0 * PER; v1 += c1 * PER; v2 += c2 * PER; fsp += (float)PER;
     }
 }
 
@@ -839,9 +838,8 @@ __device__ __forceinline__ int64_t floor_div64(int64_t num, int64_t den)
 // [min, max) of the major axis: the pixel that contains the exact line point there.  The pixel is a
 // sample of the triangle's plane at its centre (depth, attributes), so the resolve below is shared
 // with fill mode.  Debug mode: one lane per triangle, no wave cooperation.
-struct WirePlane { int32_t A1, B1, A2, B2; int64_t C1, C2; float z0, dz1, dz2, inv_area; };
 template <int TILE>
-__device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, int32_t aX, int32_t aY, int32_t bX, int32_t bY, const WirePlane& t,
+__device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, int32_t aX, int32_t aY, int32_t bX, int32_t bY, const ZPlane& zp,
                                         int ox, int oy, int bx0, int by0, int bx1, int by1, uint32_t ord)
 {
     const int64_t dX = (int64_t)bX - aX, dY = (int64_t)bY - aY;
@@ -862,9 +860,7 @@ __device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, int
             if (q < bx0 || q > bx1) continue;
             px = (int)q; py = p;
         }
-        const int32_t PX = px * 256 + 128, PY = py * 256 + 128;
-        const int64_t E1 = edge_eval(t.A1, t.B1, t.C1, PX, PY), E2 = edge_eval(t.A2, t.B2, t.C2, PX, PY);
-        cover_pixel<int64_t, TILE>(vis, px - ox, py - oy, E1, E2, 0, 0, t.z0, t.dz1, t.dz2, t.inv_area, ord);
+        cover_pixel<TILE>(vis, px - ox, py - oy, (float)(px - ox + zp.offx), (float)(py - oy + zp.offy), zp, ord);
     }
 }
 
@@ -892,8 +888,19 @@ extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
 #define VR_PROF_ADD(i, v) do { } while (0)
 #endif
 
+// Workgroup size of the tile pass.  The visibility buffer (32 KB for a 64-pixel tile) admits four workgroups per CU;
+// how many waves that is per SIMD follows from the workgroup's size (256 threads: 4, 320: 5, 384: 6) if the kernel's
+// registers allow as many (<= 128 / 96 / 80).
+#ifndef VR_RASTER_THREADS
+#define VR_RASTER_THREADS 256
+#endif
+constexpr int kRT = VR_RASTER_THREADS, kRW = kRT / 64;
+#ifndef VR_RASTER_WAVES_PER_EU
+#define VR_RASTER_WAVES_PER_EU kRW
+#endif
+
 template <bool WIRE, int TILE, bool SAME>
-__global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
+__global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
@@ -908,22 +915,27 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __shared__ float thr[kThrTabSize];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VR_LDS_PAD      // experiments only: extra LDS per workgroup = fewer workgroups per CU (occupancy sensitivity of the tile pass)
+    __shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
+    if (a.w < 0) lds_pad[tid] = (uint32_t)tid;
+    if (a.h < 0) g_diff[0] = lds_pad[tid ^ 1];
+#endif
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
-    for (int i = tid; i < (kEncTabSize + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
+    for (int i = tid; i < (kEncTabSize + 3) / 4; i += kRT) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
-    thr[tid] = thr_g[tid];
+    if (tid < 256) thr[tid] = thr_g[tid];
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     if (a.assume_cleared && ox + TILE <= a.w && oy + TILE <= a.h) {       // interior tile of a cleared target: one constant
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 cv = { 0x3f800000ffffffffull, 0x3f800000ffffffffull };
-        for (int i = tid; i < TILE * TILE / 2; i += 256) reinterpret_cast<u64x2*>(vis)[i] = cv;
+        for (int i = tid; i < TILE * TILE / 2; i += kRT) reinterpret_cast<u64x2*>(vis)[i] = cv;
     } else
-    for (int i = tid; i < TILE * TILE; i += 256) {
+    for (int i = tid; i < TILE * TILE; i += kRT) {
         const int lx = i & (TILE - 1), ly = i / TILE;
         const int gx = ox + lx, gy = oy + ly;
         unsigned long long key = 0ull;                         // outside the target: nothing passes
@@ -939,9 +951,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
     const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + TILE - 1, a.vx1), by1 = min(oy + TILE - 1, a.vy1);
     const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
-    for (uint32_t base = 0; base < n; base += 256) {
-        // consecutive bin entries go to different waves so that a short list still uses all four
-        const uint32_t idx = base + (uint32_t)(lane * 4 + wave);
+    for (uint32_t base = 0; base < n; base += kRT) {
+        // consecutive bin entries go to different waves so that a short list still uses all of them
+        const uint32_t idx = base + (uint32_t)(lane * kRW + wave);
         bool valid = idx < n && (off + idx) < a.bin_capacity;
         uint32_t key = 0;
         uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
@@ -952,9 +964,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         }
         const int32_t A0 = (int32_t)g0.x, B0 = (int32_t)g0.y, A1 = (int32_t)g1.x, B1 = (int32_t)g1.y, A2 = (int32_t)g2.x, B2 = (int32_t)g2.y;
         const int64_t C0 = rec_c(g0), C1 = rec_c(g1), C2 = rec_c(g2);
-        const float z0 = __uint_as_float(g3.x), dz1 = __uint_as_float(g3.y), dz2 = __uint_as_float(g3.z), ia = __uint_as_float(g3.w);
-        const int bias0 = (int)(g4.z & 1u), bias1 = (int)((g4.z >> 1) & 1u), bias2 = (int)((g4.z >> 2) & 1u);
-        const bool is_small = (g4.z & 8u) != 0u;
+        const int bias0 = (int)(g3.w & 1u), bias1 = (int)((g3.w >> 1) & 1u), bias2 = (int)((g3.w >> 2) & 1u);
+        const bool is_small = (g3.w & 8u) != 0u;
+        // the depth plane, with this tile's origin relative to the plane's anchor (the box's first pixel)
+        ZPlane zp;
+        zp.z0 = __uint_as_float(g3.x); zp.zx = __uint_as_float(g3.y); zp.zy = __uint_as_float(g3.z);
+        zp.offx = ox - (int)(g4.x & 0xffffu); zp.offy = oy - (int)(g4.x >> 16);
         // the triangle's pixel box inside this tile (never empty for a binned triangle; checked all the same)
         const int tx0 = max((int)(g4.x & 0xffffu), bx0), ty0 = max((int)(g4.x >> 16), by0);
         const int tx1 = min((int)(g4.y & 0xffffu), bx1), ty1 = min((int)(g4.y >> 16), by1);
@@ -965,10 +980,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 uint32_t i0, i1, i2;
                 entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
                 const ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
-                WirePlane wp; wp.A1 = A1; wp.B1 = B1; wp.A2 = A2; wp.B2 = B2; wp.C1 = C1; wp.C2 = C2; wp.z0 = z0; wp.dz1 = dz1; wp.dz2 = dz2; wp.inv_area = ia;
-                wire_edge<TILE>(vis, s0.X, s0.Y, s1.X, s1.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
-                wire_edge<TILE>(vis, s1.X, s1.Y, s2.X, s2.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
-                wire_edge<TILE>(vis, s2.X, s2.Y, s0.X, s0.Y, wp, ox, oy, tx0, ty0, tx1, ty1, order);
+                wire_edge<TILE>(vis, s0.X, s0.Y, s1.X, s1.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
+                wire_edge<TILE>(vis, s1.X, s1.Y, s2.X, s2.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
+                wire_edge<TILE>(vis, s2.X, s2.Y, s0.X, s0.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
             }
             continue;                   // covered; no fill sweeps
         }
@@ -995,9 +1009,9 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         }
         if (tiny) {
             if (fits32) sweep_small<int32_t, TILE>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, sx0, sy0, sx1, sy1, sx2, sy2,
-                                                    bias0, bias1, bias2, x0, y0, x1, y1, z0, dz1, dz2, ia, order);
+                                                    bias0, bias1, bias2, x0, y0, x1, y1, zp, order);
             else sweep_small<int64_t, TILE>(vis, e0, e1, e2, (int64_t)A0 * 256, (int64_t)B0 * 256, (int64_t)A1 * 256, (int64_t)B1 * 256,
-                                             (int64_t)A2 * 256, (int64_t)B2 * 256, bias0, bias1, bias2, x0, y0, x1, y1, z0, dz1, dz2, ia, order);
+                                             (int64_t)A2 * 256, (int64_t)B2 * 256, bias0, bias1, bias2, x0, y0, x1, y1, zp, order);
         }
         VR_PROF_MARK(2);
         bool rowp = false;
@@ -1006,6 +1020,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
         // handed to the lanes 64 at a time; a lane fetches its row's triangle from the owning lane (ds_bpermute) and walks
         // the row's pixels.  Lane utilisation no longer depends on how many triangles the bin holds or how they are shaped.
         const bool row_ok = valid && !tiny && is_small;
+        // (offx, offy) in one word for the shuffles / broadcasts below: each fits 16 bits (|tile origin - anchor| < 16384)
+        const uint32_t offs = ((uint32_t)zp.offx & 0xffffu) | ((uint32_t)zp.offy << 16);
         if (__popcll(__ballot(row_ok)) >= kRowMin) {
             rowp = row_ok;
             const int rows = rowp ? bh : 0;
@@ -1019,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                 const int32_t f1 = ((int32_t)e1 + __mul24(sy1, y0)) + (__mul24(sx1, x0) - bias1);
                 const int32_t f2 = ((int32_t)e2 + __mul24(sy2, y0)) + (__mul24(sx2, x0) - bias2);
                 const int start = incl - rows;
-                const uint32_t xb = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)bias1 << 24) | ((uint32_t)bias2 << 25);
+                const uint32_t xb = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16);
                 for (int cb = 0; cb < R; cb += 64) {
                     const int r = cb + lane;
                     int tl = 0;                                   // number of lanes whose rows end at or before r = the owning lane
@@ -1033,14 +1049,18 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
                     int32_t v0 = __shfl(f0, tl) + __mul24(__shfl(sy0, tl), j);
                     int32_t v1 = __shfl(f1, tl) + __mul24(__shfl(sy1, tl), j);
                     int32_t v2 = __shfl(f2, tl) + __mul24(__shfl(sy2, tl), j);
-                    const float qz0 = __shfl(z0, tl), qdz1 = __shfl(dz1, tl), qdz2 = __shfl(dz2, tl), qia = __shfl(ia, tl);
+                    ZPlane qz;
+                    qz.z0 = __shfl(zp.z0, tl); qz.zx = __shfl(zp.zx, tl); qz.zy = __shfl(zp.zy, tl);
+                    const uint32_t qo = (uint32_t)__shfl((int)offs, tl);
+                    qz.offx = (int)(int16_t)(qo & 0xffffu); qz.offy = (int)(int16_t)(qo >> 16);
                     const uint32_t qord = (uint32_t)__shfl((int)order, tl);
-                    const int qb1 = (int)((qb >> 24) & 1u), qb2 = (int)((qb >> 25) & 1u);
                     const int y = (int)((qb >> 16) & 255u) + j, xe = (int)((qb >> 8) & 255u);
                     int x = (int)(qb & 255u);
+                    const float fy = (float)(y + qz.offy);
+                    float fx = (float)(x + qz.offx);
                     while (__any(act && x <= xe)) {
-                        if (act && x <= xe && (v0 | v1 | v2) >= 0) cover_pixel<int32_t, TILE>(vis, x, y, v1, v2, qb1, qb2, qz0, qdz1, qdz2, qia, qord);
-                        v0 += qx0; v1 += qx1; v2 += qx2; x++;
+                        if (act && x <= xe && (v0 | v1 | v2) >= 0) cover_pixel<TILE>(vis, x, y, fx, fy, qz, qord);
+                        v0 += qx0; v1 += qx1; v2 += qx2; x++; fx += 1.0f;
                     }
                 }
             }
@@ -1056,22 +1076,24 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
             big &= big - 1;
 #define BC(v) __builtin_amdgcn_readlane((int)(v), src)
 #define BC64(v) (((int64_t)BC((int32_t)((v) >> 32)) << 32) | (int64_t)(uint32_t)BC((int32_t)(uint32_t)(v)))
-            const uint32_t m = (uint32_t)BC(misc), bx = (uint32_t)BC(box), ord = (uint32_t)BC(order);
-            const float bz0 = __int_as_float(BC(__float_as_int(z0))), bdz1 = __int_as_float(BC(__float_as_int(dz1)));
-            const float bdz2 = __int_as_float(BC(__float_as_int(dz2))), bia = __int_as_float(BC(__float_as_int(ia)));
+            const uint32_t m = (uint32_t)BC(misc), bx = (uint32_t)BC(box), ord = (uint32_t)BC(order), bo = (uint32_t)BC(offs);
+            ZPlane bz;
+            bz.z0 = __int_as_float(BC(__float_as_int(zp.z0))); bz.zx = __int_as_float(BC(__float_as_int(zp.zx)));
+            bz.zy = __int_as_float(BC(__float_as_int(zp.zy)));
+            bz.offx = (int)(int16_t)(bo & 0xffffu); bz.offy = (int)(int16_t)(bo >> 16);
             const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
             const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
             if (m & 8u) {
                 if (max(qx1 - qx0, qy1 - qy0) + 1 >= min(kWalkMin, TILE - 4))
                     sweep_walk<TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
-                                     BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
+                                     BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
                 else
                     sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
-                                       BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
+                                       BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
             } else {
                 const int64_t a0 = BC(A0), bb0 = BC(B0), a1 = BC(A1), bb1 = BC(B1), a2 = BC(A2), bb2 = BC(B2);
                 sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), a0 * 256, bb0 * 256, a1 * 256, bb1 * 256, a2 * 256, bb2 * 256,
-                                   b0, b1, b2, qx0, qy0, qx1, qy1, bz0, bdz1, bdz2, bia, ord);
+                                   b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
             }
 #undef BC64
 #undef BC
@@ -1081,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     __syncthreads();
     VR_PROF_MARK(5);
 
-    // ---- resolve: shade each pixel's winner once, write 4-pixel groups ------------------
+    // ---- resolve: shade each pixel's winner once ------------------
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
     // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K)
@@ -1098,128 +1120,91 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevTex hm, DevTex 
     // did when a lane owned four pixels of a row.  The L1 is what this phase runs against - its tag look-ups were busy
     // 63 % of the kernel's cycles plus 30 % stalled (TCP_TOTAL_CACHE_ACCESSES, TCP_PENDING_STALL_CYCLES), 22 look-ups per
     // fetch instruction - not the vector pipes.
-    for (int g = tid; g < TILE * TILE / 4; g += 256) {
-        const int lx = g % TILE, ly0 = (g / TILE) * 4;
-        const int gx = ox + lx, gy0 = oy + ly0;
-        if (gy0 >= a.h || gx >= a.w) continue;
-        uint32_t covered = 0;
-        float dep[4]; uint32_t dif[4], nn0[4], nn1[4];
-        uint32_t prev = 0xffffffffu;
-        // the winner's record (groups 5..11).  The two edge functions that give the barycentrics are evaluated and stepped in
-        // double precision: every term is an integer (or half of one) below 2^52 (|A|, |B| < 2^23, |P - vertex| < 2^28), so
-        // the arithmetic is exact and v_cvt_f32_f64 rounds the exact edge value once - the same float as (float)(int64) - in 2
-        // instructions per edge and pixel for triangles of any size, and a change of triangle costs four fp64 FMAs, no integer
-        // multiply-adds or conversions.  Giants beyond that (clipped at the guard band) take the int64 path.
-        const uint4* __restrict__ rp = recs;
-        // (deliberately not initialised: the first covered pixel of a group always loads its record - prev matches no key -
-        // and zeroing 22 registers per group is 6 instructions per pixel)
-        bool dok;
-        double d1, d2, sy1, sy2;
-        const double pxd = (double)gx + 0.5, pyd = (double)gy0 + 0.5;
-        float ia, iw0, iw1, iw2, wx0, wx1, wx2, wz0, wz1, wz2;
-        float ddenx, ddeny, nxx, nzx, nxy, nzy;
-        // the column's four visibility words ahead of the per-pixel control flow
-        const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned long long key = keys[k];
-            const uint32_t low = (uint32_t)key;
-            dep[k] = __uint_as_float((uint32_t)(key >> 32)); dif[k] = 0; nn0[k] = 0; nn1[k] = 0;
-            if (low == 0xffffffffu || gy0 + k >= a.h) continue;
-            covered |= 1u << k;
-            if (a.depth_only) continue;
-            if (low != prev) {                                    // neighbours usually share the triangle
-                rp = recs + rec_index(key_of(low), hard_first, rec_hard_base) * kRecGroups;
-                const uint4 g5 = rp[5], g6 = rp[6], g7 = rp[7], g8 = rp[8];
-                const double2 ea = reinterpret_cast<const double2*>(rp)[9], eb = reinterpret_cast<const double2*>(rp)[10],
-                              ec = reinterpret_cast<const double2*>(rp)[11];
-                // edge values at the column's first pixel centre (gx + 0.5, gy0 + 0.5) in pixel units: E = 256 A x + 256 B y + C
-                sy1 = ea.y; sy2 = ec.x;
-                d1 = __builtin_fma(ea.x, pxd, __builtin_fma(sy1, pyd, eb.x));
-                d2 = __builtin_fma(eb.y, pxd, __builtin_fma(sy2, pyd, ec.y));
-                dok = d1 == d1;                                  // NaN: a giant triangle, exact only in int64
-                iw0 = __uint_as_float(g5.x); iw1 = __uint_as_float(g5.y); iw2 = __uint_as_float(g5.z); ddenx = __uint_as_float(g5.w);
-                wx0 = __uint_as_float(g6.x); wx1 = __uint_as_float(g6.y); wx2 = __uint_as_float(g6.z); ddeny = __uint_as_float(g6.w);
-                wz0 = __uint_as_float(g7.x); wz1 = __uint_as_float(g7.y); wz2 = __uint_as_float(g7.z); ia = __uint_as_float(g7.w);
-                nxx = __uint_as_float(g8.x); nzx = __uint_as_float(g8.y); nxy = __uint_as_float(g8.z); nzy = __uint_as_float(g8.w);
-                prev = low;
-            }
-            float fe1, fe2;
-            if (dok) { fe1 = (float)__builtin_fma(sy1, (double)k, d1); fe2 = (float)__builtin_fma(sy2, (double)k, d2); }
-            else {
-                const uint4 g1 = rp[1], g2 = rp[2];
-                const int32_t PX = gx * 256 + 128, PY = (gy0 + k) * 256 + 128;
-                fe1 = (float)edge_eval((int32_t)g1.x, (int32_t)g1.y, rec_c(g1), PX, PY);
-                fe2 = (float)edge_eval((int32_t)g2.x, (int32_t)g2.y, rec_c(g2), PX, PY);
-            }
-            // perspective-correct world xz and its screen-space derivatives (terrain_ps.hlsl interpolants)
-            Attr p;
-            {
-                const float l1 = fe1 * ia, l2 = fe2 * ia;
-                const float l0 = (1.0f - l1) - l2;
-                const float q0 = l0 * iw0, q1 = l1 * iw1, q2 = l2 * iw2;
-                const float den = (q0 + q1) + q2;
-                // 1.0f / den: den = the interpolated 1/w of a point in front of the near plane, far inside the safe range;
-                // anything else (a wire pixel far off its triangle's plane) takes the general division
-                const float aden = fabsf(den);
-                float r;
-                if (__any(!(aden > 0x1p-60f && aden < 0x1p60f))) r = 1.0f / den;       // (wave-uniform, practically never taken)
-                else r = vr_rcp_exact(den);
-                const float b0 = q0 * r, b1 = q1 * r, b2 = q2 * r;
-                p.wx = (b0 * wx0 + b1 * wx1) + b2 * wx2;
-                p.wz = (b0 * wz0 + b1 * wz1) + b2 * wz2;
-                p.dwxdx = (nxx - p.wx * ddenx) * r; p.dwzdx = (nzx - p.wz * ddenx) * r;
-                p.dwxdy = (nxy - p.wx * ddeny) * r; p.dwzdy = (nzy - p.wz * ddeny) * r;
-            }
-            pixel_shader<SAME>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif[k], nn0[k], nn1[k]);
-        }
-        if (!a.assume_cleared && covered == 0) continue;          // nothing of this column was drawn
-        // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
-        // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
-        // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
-        // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
-        // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
-        // A wave's store covers 64 (32) neighbouring pixels of a row: 256 contiguous bytes per 4-byte plane.
-        // The five planes of a vr_gbuffer are one allocation: one buffer resource, the plane as the scalar offset and one
-        // 32-bit pixel offset per store instead of a 64-bit address per plane and pixel (15 fewer instructions per pixel).
-        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-        if (gb_small) {
-            constexpr int aux = TILE == 64 ? 2 : 0;               // nt
-            uint32_t pix = (uint32_t)gy0 * (uint32_t)a.w + (uint32_t)gx;
-#pragma unroll
-            for (int k = 0; k < 4; k++, pix += (uint32_t)a.w) {
-                const bool c = (covered >> k) & 1u;
-                if (gy0 + k >= a.h || (!c && !a.assume_cleared)) continue;       // keep what the target holds
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dep[k]), rgb, pix << 2, 0, aux);
-                if (!a.depth_only) {
-                    __builtin_amdgcn_raw_buffer_store_b32(dif[k], rgb, pix << 2, o_diff, aux);
-                    __builtin_amdgcn_raw_buffer_store_b32(c ? spec_const : 0u, rgb, pix << 2, o_spec, aux);
-                    const u2 nv = { nn0[k], nn1[k] }, zv = { 0u, 0u };
-                    __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix << 3, o_nrm, aux);
-                    __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix << 3, o_emi, aux);
-                }
-            }
-            continue;
-        }
+    // Every pixel leaves through its stores as soon as it is shaded (nothing is kept for the end of the column): a wave's
+    // store covers 64 (32) neighbouring pixels of a row, 256 contiguous bytes per 4-byte plane.
+    // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
+    // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
+    // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
+    // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
+    // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
+    // The five planes of a vr_gbuffer are one allocation: one buffer resource, the plane as the scalar offset and one
+    // 32-bit pixel offset per store instead of a 64-bit address per plane and pixel.
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    constexpr int aux = TILE == 64 ? 2 : 0;               // nt
 #define ST1(ptr, v) do { if (TILE == 64) __builtin_nontemporal_store((v), (ptr)); else *(ptr) = (v); } while (0)
 #define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); \
                               else *reinterpret_cast<u2*>(ptr) = v_; } while (0)
+    for (int g = tid; g < TILE * TILE / 4; g += kRT) {
+        const int lx = g % TILE, ly0 = (g / TILE) * 4;
+        const int gx = ox + lx, gy0 = oy + ly0;
+        if (gy0 >= a.h || gx >= a.w) continue;
+        uint32_t prev = 0xffffffffu;
+        // the winner's planes (record groups 5..7) and this column's offset from their anchor
+        // (deliberately not initialised: the first covered pixel of a group always loads its record - prev matches no key)
+        float q0, qx, qy, nx0, nxx, nxy, nz0, nzx, nzy, fdx, fdy0;
+        // the column's four visibility words ahead of the per-pixel control flow
+        const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
+        uint32_t pix = (uint32_t)gy0 * (uint32_t)a.w + (uint32_t)gx;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool c = (covered >> k) & 1u;
-            if (gy0 + k >= a.h || (!c && !a.assume_cleared)) continue;       // keep what the target holds
-            const size_t pix = (size_t)(gy0 + k) * a.w + gx;
-            ST1(g_depth + pix, dep[k]);
-            if (!a.depth_only) {
-                ST1(g_diff + pix, dif[k]);
-                ST1(g_spec + pix, c ? spec_const : 0u);
-                ST2(g_nrm + pix, nn0[k], nn1[k]);
-                ST2(g_emi + pix, 0u, 0u);
+        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w) {
+            const unsigned long long key = keys[k];
+            const uint32_t low = (uint32_t)key;
+            if (gy0 + k >= a.h) continue;
+            const bool cov = low != 0xffffffffu;
+            if (!cov && !a.assume_cleared) continue;               // keep what the target holds
+            const uint32_t dep = (uint32_t)(key >> 32);
+            uint32_t dif = 0, nn0 = 0, nn1 = 0;
+            if (cov && !a.depth_only) {
+                if (low != prev) {                                    // neighbours usually share the triangle
+                    const uint4* __restrict__ rp = recs + rec_index(key_of(low), hard_first, rec_hard_base) * kRecGroups;
+                    const uint4 g5 = rp[5], g6 = rp[6], g7 = rp[7];
+                    q0 = __uint_as_float(g5.x); qx = __uint_as_float(g5.y); qy = __uint_as_float(g5.z);
+                    nx0 = __uint_as_float(g6.x); nxx = __uint_as_float(g6.y); nxy = __uint_as_float(g6.z);
+                    nz0 = __uint_as_float(g7.x); nzx = __uint_as_float(g7.y); nzy = __uint_as_float(g7.z);
+                    fdx = (float)(gx - (int)(g5.w & 0xffffu)); fdy0 = (float)(gy0 - (int)(g5.w >> 16));
+                    prev = low;
+                }
+                // perspective-correct world xz and its screen-space derivatives (oracle: interp)
+                Attr p;
+                {
+                    const float fdy = fdy0 + (float)k;              // exact: small integers
+                    const float q = plane_at(q0, qx, qy, fdx, fdy);
+                    // 1.0f / q: q = the interpolated 1/w of a point in front of the near plane, far inside the safe range;
+                    // anything else (a wire pixel far off its triangle's plane) takes the general division
+                    const float aq = fabsf(q);
+                    float r;
+                    if (__any(!(aq > 0x1p-60f && aq < 0x1p60f))) r = 1.0f / q;           // (wave-uniform, practically never taken)
+                    else r = vr_rcp_exact(q);
+                    p.wx = plane_at(nx0, nxx, nxy, fdx, fdy) * r;
+                    p.wz = plane_at(nz0, nzx, nzy, fdx, fdy) * r;
+                    p.dwxdx = __builtin_fmaf(-p.wx, qx, nxx) * r; p.dwzdx = __builtin_fmaf(-p.wz, qx, nzx) * r;
+                    p.dwxdy = __builtin_fmaf(-p.wx, qy, nxy) * r; p.dwzdy = __builtin_fmaf(-p.wz, qy, nzy) * r;
+                }
+                pixel_shader<SAME>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
+            }
+            if (gb_small) {
+                __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix << 2, 0, aux);
+                if (!a.depth_only) {
+                    __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix << 2, o_diff, aux);
+                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix << 2, o_spec, aux);
+                    const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
+                    __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix << 3, o_nrm, aux);
+                    __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix << 3, o_emi, aux);
+                }
+            } else {
+                const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
+                ST1(g_depth + p64, __uint_as_float(dep));
+                if (!a.depth_only) {
+                    ST1(g_diff + p64, dif);
+                    ST1(g_spec + p64, cov ? spec_const : 0u);
+                    ST2(g_nrm + p64, nn0, nn1);
+                    ST2(g_emi + p64, 0u, 0u);
+                }
             }
         }
+    }
 #undef ST1
 #undef ST2
-    }
     VR_PROF_MARK(6);
 }
 
@@ -1260,12 +1245,13 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
 }
 
 // select -> vertex -> setup -> clip -> scan -> fill into `g`, on the geometry stream
-static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_from, const vr_view* view, const vr_render_params* rp,
+static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, const vr_view* view, const vr_render_params* rp,
                            const RasterArgs& a, const PartTables* pt)
 {
     vr_context* ctx = t->ctx;
     // this chain's stream: the terrain's two geometry streams take turns.  Whatever the set did before on the other one
-    // is ordered by the events below (its tile pass waited for its geometry, and this chain waits for that tile pass).
+    // is ordered by the events below: its previous chain (consumed by a tile pass or not), the tile pass that read it, and
+    // a lock_view copy of its selection into another set.
     g.stream = t->geo_streams[t->geo_turn++ & 1u];
     hipStream_t s = ctx->stream, gs = g.stream;
     if (!ctx->async_geometry) {          // single-stream mode: order the geometry behind everything queued so far
@@ -1273,6 +1259,8 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
         g.main_dep_pending = true;
     }
     // after the tile pass that last read this set, and after anything the context's stream did to the terrain
+    if (g.geo_recorded) VR_HIP(hipStreamWaitEvent(gs, g.ev_geo_done, 0));
+    if (g.sel_read_pending) { VR_HIP(hipStreamWaitEvent(gs, g.ev_sel_read, 0)); g.sel_read_pending = false; }
     if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.raster_done, 0));
     if (g.main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); g.main_dep_pending = false; }
     int rc;
@@ -1286,6 +1274,9 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
         VR_HIP(hipMemcpyAsync(g.d_node_ids, selection_from->d_node_ids, (size_t)t->p.max_instances * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
         VR_HIP(hipMemcpyAsync(g.d_instances, selection_from->d_instances, (size_t)t->p.max_instances * sizeof(vr_instance), hipMemcpyDeviceToDevice, gs));
         VR_HIP(hipMemcpyAsync(g.d_counters, selection_from->d_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
+        // the source set's next writer (a select into it, on either stream) must not overtake these copies
+        VR_HIP(hipEventRecord(selection_from->ev_sel_read, gs));
+        selection_from->sel_read_pending = true;
         g.have_selection = true;
     }
     const int n_tiles = a.rtx * a.rty;
@@ -1323,6 +1314,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, const GeoSet* selection_fro
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
+    g.geo_recorded = true;
     VR_HIP(hipGetLastError());
     return VR_OK;
 }
@@ -1392,10 +1384,10 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     const bool use_prepared = gi >= 0;
     if (!use_prepared) gi = vr_terrain_pick_set(t);
     GeoSet& g = t->sets[gi];
-    const GeoSet& last = t->sets[t->cur];
+    GeoSet& last = t->sets[t->cur];
     g.prepared = false;
     if (!use_prepared) {
-        const GeoSet* sel = (rp->lock_view && last.have_selection) ? &last : nullptr;
+        GeoSet* sel = (rp->lock_view && last.have_selection) ? &last : nullptr;
         if ((rc = launch_geometry(t, g, sel, view, rp, a, pt))) return rc;
     }
     t->cur = gi;
@@ -1415,7 +1407,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         const bool same = t->height.w0 == t->albedo.w0 && t->height.h0 == t->albedo.h0 && t->height.levels == t->albedo.levels;
         auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32, false> : (same ? k_raster<false, 32, true> : k_raster<false, 32, false>))
                                       : (a.wireframe ? k_raster<true, 64, false> : (same ? k_raster<false, 64, true> : k_raster<false, 64, false>));
-        VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(256), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
+        VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is

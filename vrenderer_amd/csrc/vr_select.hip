@@ -452,7 +452,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
         VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
         VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
-        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * 12 * sizeof(uint4));
+        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * kRecGroups * sizeof(uint4));
         VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
         VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
         VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
@@ -463,6 +463,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_HIP(hipMemsetAsync(g.d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
         VR_HIP(hipEventCreateWithFlags(&g.ev_geo_done, hipEventDisableTiming));
         VR_HIP(hipEventCreateWithFlags(&g.ev_raster_done, hipEventDisableTiming));
+        VR_HIP(hipEventCreateWithFlags(&g.ev_sel_read, hipEventDisableTiming));
     }
     VR_HIP(hipStreamSynchronize(ctx->stream));
     {   // lowest priority: geometry fills in around the tile / lighting passes (highest priority measured the same:
@@ -492,6 +493,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
     for (GeoSet& g : t->sets) {
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
+        if (g.ev_sel_read) (void)hipEventDestroy(g.ev_sel_read);
         (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
         (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
         (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
@@ -564,10 +566,15 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
     GeoSet& g = t->sets[gi];
     g.stream = t->geo_streams[t->geo_turn++ & 1u];
     if (g.main_dep_pending) { VR_HIP(hipStreamWaitEvent(g.stream, t->ev_main_dep, 0)); g.main_dep_pending = false; }
+    // the set's previous chain may have run on the other geometry stream and may never have been rastered
+    if (g.geo_recorded) VR_HIP(hipStreamWaitEvent(g.stream, g.ev_geo_done, 0));
+    if (g.sel_read_pending) { VR_HIP(hipStreamWaitEvent(g.stream, g.ev_sel_read, 0)); g.sel_read_pending = false; }
     if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(g.stream, g.raster_done, 0));
     g.prepared = false;
     int rc = vr_select_launch(t, g, view, max_height, g.stream);
     if (rc) return rc;
+    VR_HIP(hipEventRecord(g.ev_geo_done, g.stream));           // this select is the set's latest writer
+    g.geo_recorded = true;
     t->cur = gi;
     if (!node_ids && !instances && !count) return VR_OK;       // stays asynchronous
     uint32_t n = 0;
@@ -600,6 +607,25 @@ extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
         VR_HIP(hipMemcpy(c.data(), g.d_tile_cursor, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         VR_HIP(hipMemcpy(o.data(), g.d_tile_offset, o.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < c.size(); i++) { const uint32_t v = c[i] - o[i]; if (v > out[6]) out[6] = v; if (v) out[7]++; }
+    }
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_debug_download_vertices(vr_terrain* t, uint32_t first, uint32_t count, float* out)
+{
+    VR_REQUIRE(t && out, "NULL argument");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    VR_HIP(hipStreamSynchronize(t->sets[t->cur].stream));
+    VR_HIP(hipStreamSynchronize(t->ctx->stream));
+    const GeoSet& g = t->sets[t->cur];
+    uint32_t n = 0;
+    VR_HIP(hipMemcpy(&n, g.d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VR_REQUIRE((uint64_t)first + count <= (uint64_t)n * kVertsPerInst, "vertex range exceeds the last draw's instances");
+    std::vector<DevVert> v(count);
+    if (count) VR_HIP(hipMemcpy(v.data(), g.d_verts + first, (size_t)count * sizeof(DevVert), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < count; i++) {
+        out[i * 6 + 0] = v[i].cx; out[i * 6 + 1] = v[i].cy; out[i * 6 + 2] = v[i].cz; out[i * 6 + 3] = v[i].cw;
+        out[i * 6 + 4] = v[i].wx; out[i * 6 + 5] = v[i].wz;
     }
     return VR_OK;
 }

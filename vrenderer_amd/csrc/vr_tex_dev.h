@@ -15,7 +15,7 @@ struct BilinearSetup { int i00, i10, i01, i11; float fx, fy; };
 __device__ __forceinline__ BilinearSetup vr_bilinear_setup(int w, int h, float u, float v)
 {
     BilinearSetup s;
-    float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    float x = __builtin_fmaf(u, (float)w, -0.5f), y = __builtin_fmaf(v, (float)h, -0.5f);     // fused, as the oracle's tex_bilinear
     float xf = floorf(x), yf = floorf(y);
     s.fx = x - xf; s.fy = y - yf;
     xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
@@ -25,49 +25,6 @@ __device__ __forceinline__ BilinearSetup vr_bilinear_setup(int w, int h, float u
     const int r0 = __mul24(y0, w), r1 = __mul24(y1, w);
     s.i00 = r0 + x0; s.i10 = r0 + x1; s.i01 = r1 + x0; s.i11 = r1 + x1;
     return s;
-}
-
-__device__ __forceinline__ float vr_bilinear_r8(const DevTex& t, int level, float u, float v)
-{
-    int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
-    const uint8_t* d = t.base + t.off[level];
-    BilinearSetup s = vr_bilinear_setup(w, h, u, v);
-    float t00 = (float)d[s.i00] / 255.0f, t10 = (float)d[s.i10] / 255.0f;
-    float t01 = (float)d[s.i01] / 255.0f, t11 = (float)d[s.i11] / 255.0f;
-    float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
-    return top + (bot - top) * s.fy;
-}
-
-// R8 bilinear tap through the quad (footprint) table: one dword load; r8 = LDS table of i/255.
-__device__ __forceinline__ float vr_bilinear_r8q(const DevTex& t, int level, float u, float v, const float* __restrict__ r8)
-{
-    const int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    float xf = floorf(x), yf = floorf(y);
-    const float fx = x - xf, fy = y - yf;
-    xf = vr_min(vr_max(xf, -1.0f), (float)w); yf = vr_min(vr_max(yf, -1.0f), (float)h);
-    const int ix = (int)xf + 1, iy = (int)yf + 1;
-    const uint32_t e = t.quad[t.qoff[level] + (uint32_t)(iy * (w + 2) + ix)];
-    const float t00 = r8[e & 255u], t10 = r8[(e >> 8) & 255u], t01 = r8[(e >> 16) & 255u], t11 = r8[e >> 24];
-    const float top = t00 + (t10 - t00) * fx, bot = t01 + (t11 - t01) * fx;
-    return top + (bot - top) * fy;
-}
-__device__ __forceinline__ float vr_trilinear_r8q(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8);
-
-// lut: 256-entry sRGB8 -> linear table (LDS or global)
-__device__ __forceinline__ void vr_bilinear_srgb(const DevTex& t, int level, float u, float v, const float* lut, float out[3])
-{
-    int w = max(1, t.w0 >> level), h = max(1, t.h0 >> level);
-    const uint32_t* d = (const uint32_t*)(t.base + t.off[level]);
-    BilinearSetup s = vr_bilinear_setup(w, h, u, v);
-    uint32_t p00 = d[s.i00], p10 = d[s.i10], p01 = d[s.i01], p11 = d[s.i11];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float t00 = lut[(p00 >> (8 * c)) & 255u], t10 = lut[(p10 >> (8 * c)) & 255u];
-        float t01 = lut[(p01 >> (8 * c)) & 255u], t11 = lut[(p11 >> (8 * c)) & 255u];
-        float top = t00 + (t10 - t00) * s.fx, bot = t01 + (t11 - t01) * s.fx;
-        out[c] = top + (bot - top) * s.fy;
-    }
 }
 
 struct LodSplit { int l0; float f; };
@@ -81,53 +38,19 @@ __device__ __forceinline__ LodSplit vr_lod_split(int levels, float lod)
     return r;
 }
 
-__device__ __forceinline__ float vr_trilinear_r8(const DevTex& t, float lod, float u, float v)
-{
-    LodSplit ls = vr_lod_split(t.levels, lod);
-    float a = vr_bilinear_r8(t, ls.l0, u, v);
-    if (ls.f > 0.0f) {
-        float b = vr_bilinear_r8(t, ls.l0 + 1, u, v);
-        a = a + (b - a) * ls.f;
-    }
-    return a;
-}
-
-__device__ __forceinline__ void vr_trilinear_srgb(const DevTex& t, float lod, float u, float v, const float* lut, float out[3])
-{
-    LodSplit ls = vr_lod_split(t.levels, lod);
-    vr_bilinear_srgb(t, ls.l0, u, v, lut, out);
-    if (ls.f > 0.0f) {
-        float b[3];
-        vr_bilinear_srgb(t, ls.l0 + 1, u, v, lut, b);
-#pragma unroll
-        for (int c = 0; c < 3; c++) out[c] = out[c] + (b[c] - out[c]) * ls.f;
-    }
-}
-
-__device__ __forceinline__ float vr_trilinear_r8q(const DevTex& t, float lod, float u, float v, const float* __restrict__ r8)
-{
-    const LodSplit ls = vr_lod_split(t.levels, lod);
-    float a = vr_bilinear_r8q(t, ls.l0, u, v, r8);
-    if (ls.f > 0.0f) {
-        const float b = vr_bilinear_r8q(t, ls.l0 + 1, u, v, r8);
-        a = a + (b - a) * ls.f;
-    }
-    return a;
-}
-
 // Implicit LOD from screen-space uv differences (isotropic, D3D11 7.18.11) with the
 // pinned cubic log2 (max error 1.1e-3 LOD) so every implementation agrees exactly.
 __device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
 {
     float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
-    float r2x = ax * ax + ay * ay, r2y = bx * bx + by * by;
+    float r2x = __builtin_fmaf(ax, ax, ay * ay), r2y = __builtin_fmaf(bx, bx, by * by);      // fused sums of squares (oracle: lod_from_derivs)
     float r2 = r2x > r2y ? r2x : r2y;
     if (!(r2 > 1.0f)) return 0.0f;
     uint32_t bits = __float_as_uint(r2);
     int e = (int)((bits >> 23) & 255u) - 127;
     if (e >= 128) return 64.0f;
     float tt = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
-    float p = tt * (1.4208646f + tt * (-0.57725066f + tt * 0.1563861f));
+    float p = tt * __builtin_fmaf(tt, __builtin_fmaf(tt, 0.1563861f, -0.57725066f), 1.4208646f);
     return 0.5f * ((float)e + p);
 }
 

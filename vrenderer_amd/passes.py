@@ -381,6 +381,15 @@ class TerrainPass:
         keys = ("nodes", "flags", "clip_subtris", "clip_verts", "clipped_tris", "bin_entries", "max_bin", "nonempty_bins")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def download_vertices(self, first_instance, num_instances=1):
+        """main_vs outputs of the last Render for whole instances: (n, 1089, 6) floats = clip xyzw + world xz (test helper)."""
+        import numpy as np
+        n = int(num_instances) * 1089
+        out = np.empty((n, 6), np.float32)
+        check(self.ctx.lib.vr_debug_download_vertices(self.handle, int(first_instance) * 1089, n, out.ctypes.data_as(C.c_void_p)),
+              "vr_debug_download_vertices")
+        return out.reshape(int(num_instances), 1089, 6)
+
     def Prepare(self, view, render_targets, render_params, partition=None):
         """Build the next frame's geometry ahead of time (overlaps the current frame's tile pass)."""
         check(self.ctx.lib.vr_terrain_prepare(self.handle, C.byref(view), render_targets.handle, C.byref(render_params),
