@@ -316,6 +316,10 @@ def main():
             frame = vr.LdrImage(ctx_post, W, H)
         else:
             frame = vr.HdrImage(ctx_post, W, H)
+        # event pairs around the collectives themselves (on the exchange stream): the first multi-GPU run can then separate
+        # the exchange from the compute it hides behind
+        xch_events = []                                            # (start, stop) per timed frame
+        xch_timed = [False]
         render_done = [torch.cuda.Event() for _ in range(nbuf)]
         comm_done = [torch.cuda.Event() for _ in range(nbuf)]       # the send buffers of slot b are free again
         gather_done = [torch.cuda.Event() for _ in range(nbuf)]     # gathered[b] is complete
@@ -399,15 +403,25 @@ def main():
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
             comm_stream.wait_event(post_done[b])                           # gathered[b] is free (no-op before first use)
+            ev = None
+            if xch_timed[0]:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                xch_events.append(ev)
             if ldr:
                 tm.ResetHistogram()
                 tm.AddFrameToHistogram(tmp, hdr_bufs[b], W, H, part)       # this rank's pixels
+                if ev: ev[0].record(comm_stream)
                 allreduce(hist_t)                                          # the real exchange step of f3: 1 KiB
+                if ev: ev[1].record(comm_stream)
                 tm.ComputeExposure(tmp)
                 tm.Render(tmp, hdr_bufs[b], ldr_bufs[b], W, H, part)       # packed RGB16F tiles -> packed RGB8 tiles
+                if ev: ev[2].record(comm_stream)
                 allgather(gathered_ldr[b], packed_ldr[b])
+                if ev: ev[3].record(comm_stream)
             else:
+                if ev: ev[0].record(comm_stream); ev[1].record(comm_stream); ev[2].record(comm_stream)
                 allgather(gathered[b].view(torch.uint8), packed[b][:half_elems].view(torch.uint8))
+                if ev: ev[3].record(comm_stream)
             gather_done[b].record(comm_stream)
             comm_done[b].record(comm_stream)
         with torch.cuda.stream(post_stream):
@@ -435,11 +449,15 @@ def main():
     side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx_comm)) if c is not ctx]
     for c in side_ctxs:
         c.timing_enable(True)
+    if use_dist:
+        xch_timed[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    if use_dist:
+        xch_timed[0] = False
     timings = ctx.timing_collect()
     ctx.timing_enable(False)
     for c in side_ctxs:
@@ -493,9 +511,18 @@ def main():
         # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 for wide
         # reads, + WRITE_SIZE; see tools/summarize_pmc.py).  They were taken on the N=1 8K workload.
         pmc, sq = {}, {}
-        pmc_file = "profiles/r02_pmc_traffic_lights.json" if tiled else "profiles/r02_pmc_traffic.json"
-        sq_file = "profiles/r02_pmc_sq_lights.json" if tiled else "profiles/r02_pmc_sq.json"
-        if world == 1 and not emu and (W, H) == (7680, 4320):
+        def newest(stem):
+            for rnd in ("r03", "r02"):
+                f = f"profiles/{rnd}_{stem}"
+                if os.path.exists(os.path.join(ROOT, f)):
+                    return f
+            return f"profiles/r02_{stem}"
+        pmc_file = newest("pmc_traffic_lights.json" if tiled else "pmc_traffic.json")
+        sq_file = newest("pmc_sq_lights.json" if tiled else "pmc_sq.json")
+        # the counter passes were taken on the default workload's launches only: with the shadow pass in the frame, on a
+        # partitioned frame or at another size the per-launch instruction counts are not those of the timed launches
+        counters_apply = world == 1 and not emu and (W, H) == (7680, 4320) and not args.shadows
+        if counters_apply:
             try:
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
             except Exception:
@@ -522,29 +549,35 @@ def main():
                                if name == "k_deferred" else "; instruction-issue bound, see roofline_valu and DESIGN.md 4")}
 
         def roof_valu(name):
-            """The bound the tile pass and the tiled lighting pass actually run against: vector-instruction issue.  achieved =
-            wave-instructions per launch (SQ_INSTS_VALU from the committed PMC pass of this command) / the live HIP-event
-            duration; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (MI355X_MICROARCH.md, issue-cost row)."""
+            """Vector-instruction issue of the tile pass / the tiled lighting pass.  achieved = wave-instructions per launch
+            (SQ_INSTS_VALU from the committed PMC pass of this command) / the live HIP-event duration.  peak = one wave64
+            instruction per cycle and SIMD, the rate tools/micro/valu_cost.hip measures for the cheapest class (v_mul/v_add/
+            v_fma_f32 with register operands, 8 waves per SIMD: 0.99 cycles; profiles/r03_valu_issue_costs.txt); most other
+            VALU instructions of these kernels (conversions, v_med3, 24-bit mads, compares, selects, anything with a scalar
+            operand) cost 2 cycles there, and a wave issues at most one VALU instruction per ~4.75 cycles, so at the 4 waves
+            per SIMD these kernels run with (registers, LDS) the ceiling is 4 / 4.75 = 0.84 per cycle: peak_at_occupancy."""
             if name not in timings or name not in sq:
                 return None
             ms, n = timings[name]
             avg_s = ms / n * 1e-3
             ach = sq[name]["SQ_INSTS_VALU"] / avg_s / 1e9
-            peak = 1024 * 2.4 / 4.0
+            peak = 1024 * 2.4
             return {"kernel": name, "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                    "frac": round(ach / peak, 4), "insts_per_launch": sq[name]["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
-                    "source": sq_file}
+                    "frac": round(ach / peak, 4), "peak_at_occupancy": round(peak * 4.0 / 4.75, 1), "frac_at_occupancy": round(ach / (peak * 4.0 / 4.75), 4),
+                    "insts_per_launch": sq[name]["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
+                    "source": sq_file + ", profiles/r03_valu_issue_costs.txt"}
 
         def roof_l1(name):
             """The tile pass's other bound: the L1's tag look-ups (one cache line per clock per CU).  achieved = look-ups per
             launch (TCP_TOTAL_CACHE_ACCESSES from the committed PMC pass of the 8K tile pass) / the live HIP-event duration;
             peak = 256 L1s x 2.4 GHz.  Only quoted for the frame the counters were collected on (8K, unsplit)."""
+            tcp_file = newest("pmc_tcp.json")
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_tcp.json")) as f:
+                with open(os.path.join(ROOT, tcp_file)) as f:
                     tcp = json.load(f)
             except OSError:
                 return None
-            if name not in timings or name not in tcp or (W, H) != (7680, 4320) or part is not None:
+            if name not in timings or name not in tcp or not counters_apply or part is not None or tiled:
                 return None
             ms, n = timings[name]
             avg_s = ms / n * 1e-3
@@ -552,9 +585,14 @@ def main():
             peak = 256 * 2.4
             return {"kernel": name, "bound": "l1-tags", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G look-ups/s",
                     "frac": round(ach / peak, 4), "lookups_per_launch": tcp[name]["TCP_TOTAL_CACHE_ACCESSES"],
-                    "pending_stall_cycles_per_launch": tcp[name]["TCP_PENDING_STALL_CYCLES"], "source": "profiles/r02_pmc_tcp.json"}
+                    "pending_stall_cycles_per_launch": tcp[name]["TCP_PENDING_STALL_CYCLES"], "source": tcp_file}
 
         roof_deferred = roof(light_kernel, DEFERRED_BYTES_PER_PX, owned_px)
+        if tiled and roof_deferred and "k_light_cull" in timings:      # config 5's lighting is two launches: price the pair
+            pair_s = (timings[light_kernel][0] / timings[light_kernel][1] + timings["k_light_cull"][0] / timings["k_light_cull"][1]) * 1e-3
+            ach = DEFERRED_BYTES_PER_PX * owned_px / pair_s / 1e9
+            roof_deferred.update({"kernel": "k_light_cull + k_deferred_tiled", "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                  "avg_us": round(pair_s * 1e6, 2)})
         roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
         out = {
             "metric": "shaded Gpixels/s at 8K terrain", "value": round(value, 3), "unit": "Gpixels/s",
@@ -574,7 +612,7 @@ def main():
             # the north-star kernel (>= 60 % HBM roofline target on the 8K deferred-lighting pass)
             "roofline": roof_deferred,
             "roofline_gbuffer_fill": roof_raster,
-            "roofline_valu": [r for r in (roof_valu("k_raster"), roof_valu(light_kernel) if tiled else None) if r],
+            "roofline_valu": [r for r in (roof_valu("k_raster"), roof_valu(light_kernel) if tiled else None) if r] if counters_apply else [],
             "roofline_l1": roof_l1("k_raster"),
             "dominant_kernel_by_time": dominant,
             "kernels": kern,
@@ -587,6 +625,23 @@ def main():
                                         "no exchange. value = frame pixels / this rank's frame period = what N such ranks deliver when the "
                                         "all-gather is fully hidden; unmeasured on N GPUs",
                                 "rank_frame_us": round(ms_per_step * 1e3, 1)}
+        if use_dist and xch_events:
+            # rank 0's own view of the exchange: event pairs on the exchange stream around the collectives themselves
+            def span(i, j):
+                return sum(ev[i].elapsed_time(ev[j]) for ev in xch_events) / len(xch_events) * 1e3
+            allreduce_us = span(0, 1) if ldr else 0.0
+            allgather_us = span(2, 3)
+            compute_us = sum(timings[k][0] / timings[k][1] * 1e3 for k in ("k_raster", light_kernel, "k_light_cull") if k in timings)
+            period_us = ms_per_step * 1e3
+            exchange_us = allreduce_us + allgather_us
+            hidden = max(0.0, min(exchange_us, compute_us + exchange_us - period_us))
+            out["exchange"] = {"exchange_us": round(exchange_us, 1), "allgather_us": round(allgather_us, 1), "allreduce_us": round(allreduce_us, 1),
+                               "rank_compute_us": round(compute_us, 1), "frame_period_us": round(period_us, 1),
+                               "overlap": round(hidden / exchange_us, 3) if exchange_us > 0 else None,
+                               "bytes_received_per_rank": int((world - 1) * (info["packed_bytes_ldr"] if ldr else info["packed_bytes"])),
+                               "what": "HIP events on rank 0's exchange stream around dist.all_reduce (256 histogram bins) and dist.all_gather_into_tensor "
+                                       "(packed tiles) of every timed frame, including the wait for the slowest peer; rank_compute_us = tile pass + "
+                                       "lighting of rank 0's tiles; overlap = share of the exchange hidden behind the next frame's rendering"}
         if verified is not None:
             out["frame_verified_against_unsplit"] = verified
         if world == 1 and not use_dist and not emu and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows:
@@ -605,6 +660,26 @@ def main():
                                     "k_raster_avg_us": j["kernels"]["k_raster"]["avg_us"]}
             except Exception as e:
                 out["frames_4k"] = {"error": repr(e)}
+        if world == 1 and not use_dist and not emu and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows and not tiled:
+            # BASELINE config 5 on one GPU: the same frame lit by 1 sun + 1023 point lights through the tiled pass (child process)
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--lights", "1024", "--steps", str(args.steps),
+                                    "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-4k"] + (["--fixed-camera"] if args.fixed_camera else []),
+                                   capture_output=True, text=True, timeout=300)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                pair_us = sum(j["kernels"][k]["avg_us"] for k in ("k_light_cull", "k_deferred_tiled") if k in j["kernels"])
+                out["lights_1024"] = {"lights": 1024, "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                                      "roofline": {"kernel": "k_light_cull + k_deferred_tiled", "bound": "hbm",
+                                                   "achieved": round(DEFERRED_BYTES_PER_PX * W * H / (pair_us * 1e-6) / 1e9, 1) if pair_us else None,
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(DEFERRED_BYTES_PER_PX * W * H / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if pair_us else None,
+                                                   "avg_us": round(pair_us, 2)},
+                                      "roofline_valu": j.get("roofline_valu"),
+                                      "kernels": {k: j["kernels"][k]["avg_us"] for k in ("k_raster", "k_light_cull", "k_deferred_tiled") if k in j["kernels"]},
+                                      "note": "not bandwidth-bound (SURVEY 7): 1.6 lights reach a covered pixel on average, ~85 instructions each"}
+            except Exception as e:
+                out["lights_1024"] = {"error": repr(e)}
         if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)

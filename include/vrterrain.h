@@ -161,7 +161,7 @@ VR_API const char* vr_version(void);
  * Renderer.cpp:326-437).  Kernel ids: */
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
        VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS,
-       VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_COUNT };
+       VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_RASTER_DEPTH, VR_K_LIGHT_CULL, VR_K_COUNT };
 VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
 /* Synchronises the stream; per kernel id: summed milliseconds and launch count since
  * the last enable/collect; resets the samples. */
@@ -180,7 +180,10 @@ VR_API void vr_render_default_params(vr_render_params* out);
 /* TerrainPass::Init + QuadTree::QuadTree/Init (TerrainPass.cpp:34-141,
  * QuadTree.cpp:10-52).  height_r8: hm_w*hm_h bytes; albedo_srgba8: al_w*al_h*4
  * bytes (decoded with sRGB=true, Renderer.cpp:55).  Both are copied to the device
- * and mip chains are generated there (Donut TextureCache mip generation). */
+ * and mip chains are generated there (Donut TextureCache mip generation).
+ * Limits: each texture at most 16384 texels on a side and 2^26 texels in all (8192 x 8192): the tile pass
+ * reads decoded copies (16 B per texel / footprint, x 4/3 for the mips) through 32-bit offsets.  Device memory
+ * held by a terrain: vr_terrain_memory_bytes(). */
 VR_API int  vr_terrain_create(vr_context* ctx, const vr_terrain_params* params,
                               const uint8_t* height_r8, int32_t hm_w, int32_t hm_h,
                               const uint8_t* albedo_srgba8, int32_t al_w, int32_t al_h,
@@ -422,6 +425,10 @@ VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
  * [2] clipper sub-triangles, [3] clipper vertices, [4] triangles sent to the clipper, [5] bin entries,
  * [6] largest bin, [7] non-empty bins */
 VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8]);
+/* Device memory a terrain holds, in bytes: out[0] textures (chains + decoded tables), out[1] per-frame geometry scratch
+ * (three rotating sets: instances, vertices, triangle records, bins - sized for params->max_instances), out[2] node
+ * heights (after vr_terrain_update_heights), out[3] the sum. */
+VR_API int vr_terrain_memory_bytes(const vr_terrain* t, uint64_t out[4]);
 /* Test helper: the vertex stage's output (main_vs, terrain_vs.hlsl:35-62) of the last vr_terrain_render for `count`
  * vertices starting at vertex `first` of the instanced draw (vertex = instance * 1089 + row * 33 + column, rows = z):
  * six floats per vertex - o_position.xyzw (clip space) and o_vtx.pos.xz (world space).  Synchronises. */

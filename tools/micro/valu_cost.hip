@@ -11,12 +11,14 @@
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 enum { M_MUL, M_ADD, M_FMA, M_FMA3, M_MAD24, M_MULLO, M_AND, M_LSHL_ADD, M_CNDMASK, M_CMP, M_CVT_I32, M_FLOOR, M_MED3, M_RCP, M_SQRT,
-       M_FMA64, M_ADD64, M_CVT_F32_F64, M_PK_FMA, M_PK_MUL, M_PK_ADD, M_MOV, M_BFE, M_MIX, M_MUL_SGPR, M_FMA_SGPR, M_CNDMASK_E64, M_CNDMASK_DEP, M_MIN_I32, M_ADD_U32, M_CVT_F32_I32, M_LDS_B64, M_COUNT };
+       M_FMA64, M_ADD64, M_CVT_F32_F64, M_PK_FMA, M_PK_MUL, M_PK_ADD, M_MOV, M_BFE, M_MIX, M_MUL_SGPR, M_FMA_SGPR, M_CNDMASK_E64, M_CNDMASK_DEP, M_MIN_I32, M_ADD_U32, M_CVT_F32_I32, M_LDS_B64, M_SUB, M_FMAC, M_MAX, M_MUL_LIT, M_MUL_INL, M_ADD_LIT, M_LSHLREV, M_OR, M_MUL_I24, M_CVT_F32_U32, M_FMAMK, M_MUL_SGPR_MIX, M_FMA_NEG, M_ADD_INL, M_SUB_U32, M_COUNT };
 static const char* kNames[M_COUNT] = { "v_mul_f32", "v_add_f32", "v_fma_f32 (a*s+s)", "v_fma_f32 (3 vgpr src)", "v_mad_u32_u24", "v_mul_lo_u32", "v_and_b32",
     "v_lshl_add_u32", "v_cndmask_b32", "v_cmp_gt_f32 (vcc)", "v_cvt_i32_f32", "v_floor_f32", "v_med3_f32", "v_rcp_f32", "v_sqrt_f32",
     "v_fma_f64", "v_add_f64", "v_cvt_f32_f64", "v_pk_fma_f32 (2 results)", "v_pk_mul_f32 (2 results)", "v_pk_add_f32 (2 results)", "v_mov_b32",
     "v_bfe_u32", "mix: 4 mul + 2 add + 2 fma", "v_mul_f32 (sgpr src)", "v_fma_f32 (v, sgpr, v)", "v_cndmask_b32 e64 (sgpr pair)",
-    "v_cmp + v_cndmask pairs (per instr)", "v_min_i32", "v_add_u32", "v_cvt_f32_i32", "ds_read_b64 (issue only)" };
+    "v_cmp + v_cndmask pairs (per instr)", "v_min_i32", "v_add_u32", "v_cvt_f32_i32", "ds_read_b64 (issue only)",
+    "v_sub_f32", "v_fmac_f32 (vop2)", "v_max_f32", "v_mul_f32 (literal 0.1)", "v_mul_f32 (inline 2.0)", "v_add_f32 (literal 0.1)", "v_lshlrev_b32 (imm 4)", "v_or_b32",
+    "v_mul_i32_i24 (vop2)", "v_cvt_f32_u32", "v_fmamk_f32 (literal)", "4 x v_mul v,v + 4 x v_mul s,v", "v_fma_f32 (-a, b, c: 3 vgpr)", "v_add_f32 (inline 1.0)", "v_sub_u32" };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, float s, int iters)
@@ -99,6 +101,30 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, fl
             else if (MODE == M_LDS_B64) { asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:8\n ds_read_b64 %2, %8 offset:16\n ds_read_b64 %3, %8 offset:24\n"
                                                        "ds_read_b64 %4, %8 offset:32\n ds_read_b64 %5, %8 offset:40\n ds_read_b64 %6, %8 offset:48\n ds_read_b64 %7, %8 offset:56\n s_waitcnt lgkmcnt(0)\n"
                                                        : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3), "=v"(d4), "=v"(d5), "=v"(d6), "=v"(d7) : "v"(ldsaddr) : "memory"); }
+            else if (MODE == M_SUB) OP2("v_sub_f32");
+            else if (MODE == M_FMAC) asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                                                  "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n" : ALLA : "v"(s), "v"(t));
+            else if (MODE == M_MAX) OP2("v_max_f32");
+            else if (MODE == M_MUL_LIT) asm volatile("v_mul_f32 %0, 0x3dcccccd, %0\n v_mul_f32 %1, 0x3dcccccd, %1\n v_mul_f32 %2, 0x3dcccccd, %2\n v_mul_f32 %3, 0x3dcccccd, %3\n"
+                                                     "v_mul_f32 %4, 0x3dcccccd, %4\n v_mul_f32 %5, 0x3dcccccd, %5\n v_mul_f32 %6, 0x3dcccccd, %6\n v_mul_f32 %7, 0x3dcccccd, %7\n" : ALLA);
+            else if (MODE == M_MUL_INL) asm volatile("v_mul_f32 %0, 2.0, %0\n v_mul_f32 %1, 2.0, %1\n v_mul_f32 %2, 2.0, %2\n v_mul_f32 %3, 2.0, %3\n"
+                                                     "v_mul_f32 %4, 2.0, %4\n v_mul_f32 %5, 2.0, %5\n v_mul_f32 %6, 2.0, %6\n v_mul_f32 %7, 2.0, %7\n" : ALLA);
+            else if (MODE == M_ADD_LIT) asm volatile("v_add_f32 %0, 0x3dcccccd, %0\n v_add_f32 %1, 0x3dcccccd, %1\n v_add_f32 %2, 0x3dcccccd, %2\n v_add_f32 %3, 0x3dcccccd, %3\n"
+                                                     "v_add_f32 %4, 0x3dcccccd, %4\n v_add_f32 %5, 0x3dcccccd, %5\n v_add_f32 %6, 0x3dcccccd, %6\n v_add_f32 %7, 0x3dcccccd, %7\n" : ALLA);
+            else if (MODE == M_ADD_INL) asm volatile("v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %2, 1.0, %2\n v_add_f32 %3, 1.0, %3\n"
+                                                     "v_add_f32 %4, 1.0, %4\n v_add_f32 %5, 1.0, %5\n v_add_f32 %6, 1.0, %6\n v_add_f32 %7, 1.0, %7\n" : ALLA);
+            else if (MODE == M_LSHLREV) asm volatile("v_lshlrev_b32 %0, 4, %0\n v_lshlrev_b32 %1, 4, %1\n v_lshlrev_b32 %2, 4, %2\n v_lshlrev_b32 %3, 4, %3\n"
+                                                     "v_lshlrev_b32 %4, 4, %4\n v_lshlrev_b32 %5, 4, %5\n v_lshlrev_b32 %6, 4, %6\n v_lshlrev_b32 %7, 4, %7\n" : ALLA);
+            else if (MODE == M_OR) OP2("v_or_b32");
+            else if (MODE == M_SUB_U32) OP2("v_sub_u32");
+            else if (MODE == M_MUL_I24) OP2("v_mul_i32_i24");
+            else if (MODE == M_CVT_F32_U32) OP1("v_cvt_f32_u32");
+            else if (MODE == M_FMAMK) asm volatile("v_fmamk_f32 %0, %0, 0x3dcccccd, %8\n v_fmamk_f32 %1, %1, 0x3dcccccd, %8\n v_fmamk_f32 %2, %2, 0x3dcccccd, %8\n v_fmamk_f32 %3, %3, 0x3dcccccd, %8\n"
+                                                   "v_fmamk_f32 %4, %4, 0x3dcccccd, %8\n v_fmamk_f32 %5, %5, 0x3dcccccd, %8\n v_fmamk_f32 %6, %6, 0x3dcccccd, %8\n v_fmamk_f32 %7, %7, 0x3dcccccd, %8\n" : ALLA : "v"(s));
+            else if (MODE == M_MUL_SGPR_MIX) asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %9, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %9, %3\n"
+                                                          "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %9, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %9, %7\n" : ALLA : "v"(s), "s"(t));
+            else if (MODE == M_FMA_NEG) asm volatile("v_fma_f32 %0, -%0, %8, %9\n v_fma_f32 %1, -%1, %8, %9\n v_fma_f32 %2, -%2, %8, %9\n v_fma_f32 %3, -%3, %8, %9\n"
+                                                     "v_fma_f32 %4, -%4, %8, %9\n v_fma_f32 %5, -%5, %8, %9\n v_fma_f32 %6, -%6, %8, %9\n v_fma_f32 %7, -%7, %8, %9\n" : ALLA : "v"(s), "v"(t));
             else if (MODE == M_MIX) asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_fma_f32 %3, %3, %8, %9\n"
                                                  "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_fma_f32 %7, %7, %8, %9\n" : ALLA : "v"(s), "v"(t));
         }

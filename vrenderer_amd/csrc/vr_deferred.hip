@@ -301,7 +301,12 @@ __device__ __forceinline__ void shade_pixel(const DeferredArgs& a, const float* 
 // Output of 4 pixels (o[2k] = r|g<<16, o[2k+1] = b, alpha 0).  Row-major frames are RGBA16F (8 B/px);
 // the packed tile buffer that goes through the all-gather drops the always-zero alpha: RGB16F, 6 B/px,
 // 25 % less xGMI traffic, restored by k_detile.
-template <bool PACKED>
+// NT (row-major frames only): streaming stores, with streaming loads in the kernel.  An 8K frame's lighting pass moves 1.2 GB
+// through the caches and leaves 265 MB of dirty lines; the NEXT frame's tile pass then finds its texel tables evicted.
+// Measured (tools/exp_serial.py, profiles/r03_serial_cache_experiment.txt): tile pass 373-379 us behind a lighting pass with
+// plain loads and stores, 325-332 us behind one that streams both (= its time with no lighting pass in between); streaming
+// only the loads or only the stores changes nothing; the lighting pass itself goes from 199-205 to 207 us.
+template <bool PACKED, bool NT = false>
 __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_index, const uint32_t o[8])
 {
     if (PACKED) {
@@ -311,8 +316,14 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
         dst[2] = make_uint2((o[5] & 0xffffu) | (o[6] << 16), (o[6] >> 16) | (o[7] << 16));
     } else {
         uint4* dst = reinterpret_cast<uint4*>(out + out_index);
-        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        if (NT) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v0 = { o[0], o[1], o[2], o[3] }, v1 = { o[4], o[5], o[6], o[7] };
+            __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(dst)); __builtin_nontemporal_store(v1, reinterpret_cast<u32x4*>(dst) + 1);
+        } else {
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 
@@ -322,7 +333,7 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
 #ifndef VR_DEFERRED_WAVES
 #define VR_DEFERRED_WAVES 4
 #endif
-template <bool PACKED, bool EXTRA, bool SHADOW = false>
+template <bool PACKED, bool EXTRA, bool SHADOW = false, bool NT = false>
 __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                    const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
@@ -352,13 +363,21 @@ __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArg
     }
     const size_t p = (size_t)py * a.w + px0;
     // issue every load first: 7 x 16 B per lane in flight
-    const float4 dz = *reinterpret_cast<const float4*>(g_depth + p);
-    const uint4 df = *reinterpret_cast<const uint4*>(g_diff + p);
-    const uint4 sp = *reinterpret_cast<const uint4*>(g_spec + p);
-    const uint4 n0 = *reinterpret_cast<const uint4*>(g_nrm + p);
-    const uint4 n1 = *reinterpret_cast<const uint4*>(g_nrm + p + 2);
-    const uint4 e0 = *reinterpret_cast<const uint4*>(g_emi + p);
-    const uint4 e1 = *reinterpret_cast<const uint4*>(g_emi + p + 2);
+    // NT: streaming (non-temporal) G-buffer reads - together with the streaming stores (store_quad) the frame's 1.2 GB then
+    // pass the caches by and the tile pass's texel tables (180 MB) are still in the Infinity Cache when the next frame's
+    // tile pass starts.  Either one alone does not help: 929 MB of reads or 265 MB of dirty lines each flush the cache.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LD16(ptr) ({ u32x4 v_; if (NT) v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr)); else v_ = *reinterpret_cast<const u32x4*>(ptr); \
+                     make_uint4(v_.x, v_.y, v_.z, v_.w); })
+    const uint4 dzu = LD16(g_depth + p);
+    const float4 dz = make_float4(__uint_as_float(dzu.x), __uint_as_float(dzu.y), __uint_as_float(dzu.z), __uint_as_float(dzu.w));
+    const uint4 df = LD16(g_diff + p);
+    const uint4 sp = LD16(g_spec + p);
+    const uint4 n0 = LD16(g_nrm + p);
+    const uint4 n1 = LD16(g_nrm + p + 2);
+    const uint4 e0 = LD16(g_emi + p);
+    const uint4 e1 = LD16(g_emi + p + 2);
+#undef LD16
 
     const float depth[4] = { dz.x, dz.y, dz.z, dz.w };
     const uint32_t dfa[4] = { df.x, df.y, df.z, df.w }, spa[4] = { sp.x, sp.y, sp.z, sp.w };
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArg
         o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
         o[2 * k + 1] = vr_float_to_half(rgb[2]);          // alpha = 0
     }
-    store_quad<PACKED>(out, out_index, o);
+    store_quad<PACKED, NT>(out, out_index, o);
 }
 
 // Generic fallback for widths that are not a multiple of 4: one pixel per lane.
@@ -466,7 +485,12 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         if (gb->w % 4 == 0) {
             const size_t quads = npx / 4;
-            auto kern = shadow ? k_deferred<false, true, true> : (extra ? k_deferred<false, true> : k_deferred<false, false>);
+            // frames whose G-buffer + HdrColor traffic exceeds the Infinity Cache (the ones the tile pass runs on 64-pixel tiles
+            // and writes with streaming stores, vr_internal.h) leave through streaming stores here as well
+            const bool nt = vr_raster_tile_shift(gb->w, gb->h) == 6;
+            auto kern = shadow ? (nt ? k_deferred<false, true, true, true> : k_deferred<false, true, true, false>)
+                               : extra ? (nt ? k_deferred<false, true, false, true> : k_deferred<false, true, false, false>)
+                                       : (nt ? k_deferred<false, false, false, true> : k_deferred<false, false, false, false>);
             VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh);
         } else {
@@ -518,7 +542,9 @@ constexpr int kSubSide = kMacroTile / kLightTile;       // 4 light tiles per mac
 constexpr int kSubTiles = kSubSide * kSubSide;
 static_assert(kSubTiles == 16 && kMacroTile == 128, "k_light_cull's lane mapping assumes 128-px macro tiles of 4x4 light tiles");
 
-// squared distance from a point to a box, compared with the light's range (attenuation is exactly 0 from the range outwards)
+// squared distance from a point to a box, compared with the light's range (attenuation is exactly 0 from the range outwards).
+// The caller passes r2 = range^2 * 1.0001: the test's own fp32 rounding (three squares and two sums, the reciprocal and
+// the square of the range: < 8 u relative) cannot turn a touching sphere into a miss.
 __device__ __forceinline__ bool sphere_touches(const float* __restrict__ box, const float pos[3], float r2)
 {
     float d2 = 0.0f;
@@ -588,7 +614,20 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
             cx0 = x0; cy0 = y0; cx1 = x0 + kMacroTile; cy1 = y0 + kMacroTile;
         }
         const bool covered = bmin <= bmax;
-        float lo[3], hi[3], far2 = 0.0f;
+        // Each corner in the shading pass's arithmetic, together with a rigorous bound of what fp32 rounding can have done
+        // to it - and to any pixel of the cell (derivation: DESIGN.md 4, "the culling boxes' pad").  With u = 2^-24 and
+        // e_j = ((cx M0j + cy M1j) + depth M2j) + M3j, |cx|, |cy| <= 1:
+        //   |e_j - exact| <= 8u T_j,  T_j = |M0j| + |M1j| + |depth M2j| + |M3j|   (4 roundings on the longest path + the
+        //                                                                          3u the window -> clip step put into cx, cy)
+        //   position_c = e_c * (1 / e_3):  |error| <= (8u T_c + |position_c| 8u T_3) / (e_3 - 8u T_3) + 2u |position_c|
+        //                                  (from e_c/e_3 - E_c/E_3 = (e_c - E_c)/E_3 - (e_c/e_3)(e_3 - E_3)/E_3, E = the exact sums)
+        // T_j grows with the depth and e_3 (= 1 / w, positive in front of the camera) is affine over the cell, so the
+        // cell's worst case is T_j at its largest depth, the smallest e_3 of its corners and the largest |position_c| of
+        // its corners.  A pixel's computed position then lies within 2 x that of the box of the computed corners (once for
+        // the corners, once for the pixel); where w cancels completely (e_3 <= 8u T_3: depth next to 1 with a far plane
+        // at 10^4 near planes away) nothing can be said and the cell keeps every light.
+        float lo[3], hi[3], dmin3, wmax[3];
+        float T[4];
         {
 #pragma clang fp contract(off)
             const float wx = (float)(corner & 1 ? min(cx1, a.w) : cx0), wy = (float)(corner & 2 ? min(cy1, a.h) : cy0);
@@ -598,20 +637,36 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
 #pragma unroll
             for (int j = 0; j < 4; j++) e4[j] = ((cx * a.c2w[0 * 4 + j] + cy * a.c2w[1 * 4 + j]) + depth * a.c2w[2 * 4 + j]) + a.c2w[3 * 4 + j];
 #pragma unroll
-            for (int c = 0; c < 3; c++) { lo[c] = hi[c] = e4[c] / e4[3]; const float dc = lo[c] - a.cam[c]; far2 += dc * dc; }
+            for (int c = 0; c < 3; c++) { lo[c] = hi[c] = e4[c] / e4[3]; wmax[c] = fabsf(lo[c]); }
+            dmin3 = e4[3];
+            const float dfar = __uint_as_float(bmax);
+#pragma unroll
+            for (int j = 0; j < 4; j++) T[j] = ((fabsf(a.c2w[0 * 4 + j]) + fabsf(a.c2w[1 * 4 + j])) + fabsf(dfar * a.c2w[2 * 4 + j])) + fabsf(a.c2w[3 * 4 + j]);
         }
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) { lo[c] = fmin1(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmax1(hi[c], __shfl_xor(hi[c], off)); }
-            far2 = fmax1(far2, __shfl_xor(far2, off));
+            for (int c = 0; c < 3; c++) {
+                lo[c] = fmin1(lo[c], __shfl_xor(lo[c], off)); hi[c] = fmax1(hi[c], __shfl_xor(hi[c], off));
+                wmax[c] = fmax1(wmax[c], __shfl_xor(wmax[c], off));
+            }
+            dmin3 = fmin1(dmin3, __shfl_xor(dmin3, off));
         }
-        // Far from the camera clip -> world loses bits (w cancels): a pixel's reconstructed position and these corners may
-        // each be off by ~1.5e-3 of their distance (2.4 units at 1600).  The pad covers both.
-        const float pad = 4.0e-3f * sqrtf(far2) + 1.0e-2f;
         if (corner == 0) {
+            const float u8 = 8.0f * 5.9604645e-8f, u2 = 2.0f * 5.9604645e-8f;
+            const float dlo = dmin3 - u8 * T[3] * 1.001f;                // (the 1.001s: this arithmetic rounds too; all terms are positive)
             // nothing covered: an empty box (no light touches it; the tile's pixels are background and receive none)
-            for (int c = 0; c < 3; c++) { s_box[b][c] = covered ? lo[c] - pad : 3.0e38f; s_box[b][3 + c] = covered ? hi[c] + pad : -3.0e38f; }
+            for (int c = 0; c < 3; c++) {
+                // pad = f(W) with W = the largest |position_c| of any pixel <= wmax + pad itself: f is affine, f(W) = alpha + beta W,
+                // so pad = (alpha + beta wmax) / (1 - beta); beta >= 1/2 means the positions themselves are noise
+                float pad = 3.0e38f;
+                if (dlo > 0.0f) {
+                    const float beta = 2.0f * 1.001f * (u8 * T[3] / dlo + u2), alpha = 2.0f * 1.001f * (u8 * T[c] / dlo);
+                    if (beta < 0.5f) pad = (alpha + beta * wmax[c]) / (1.0f - beta) * 1.001f;
+                }
+                if (!(pad < 3.0e38f)) pad = 3.0e38f;
+                s_box[b][c] = covered ? fmax1(lo[c] - pad, -3.0e38f) : 3.0e38f; s_box[b][3 + c] = covered ? fmin1(hi[c] + pad, 3.0e38f) : -3.0e38f;
+            }
             if (covered && b < kSubTiles) atomicOr(&s_covered, 1u << b);
         }
     }
@@ -697,7 +752,7 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
 #ifndef VR_TILED_PXB
 #define VR_TILED_PXB 1
 #endif
-template <bool PACKED, int PXB>
+template <bool PACKED, int PXB, bool NT = false>
 __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const DevLight* __restrict__ lights,
                                                          const float* __restrict__ g_depth, const uint32_t* __restrict__ g_diff,
                                                          const uint32_t* __restrict__ g_spec, const uint2* __restrict__ g_nrm,
@@ -735,13 +790,18 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
     uint32_t dfa[4] = { 0, 0, 0, 0 }, spa[4] = { 0, 0, 0, 0 }, na[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ea[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (inside) {
         const size_t p = (size_t)py * a.w + px0;
-        const float4 dz = *reinterpret_cast<const float4*>(g_depth + p);
-        const uint4 df = *reinterpret_cast<const uint4*>(g_diff + p);
-        const uint4 sp = *reinterpret_cast<const uint4*>(g_spec + p);
-        const uint4 n0 = *reinterpret_cast<const uint4*>(g_nrm + p);
-        const uint4 n1 = *reinterpret_cast<const uint4*>(g_nrm + p + 2);
-        const uint4 e0 = *reinterpret_cast<const uint4*>(g_emi + p);
-        const uint4 e1 = *reinterpret_cast<const uint4*>(g_emi + p + 2);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // NT: streaming loads, as in k_deferred
+#define LD16(ptr) ({ u32x4 v_; if (NT) v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr)); else v_ = *reinterpret_cast<const u32x4*>(ptr); \
+                     make_uint4(v_.x, v_.y, v_.z, v_.w); })
+        const uint4 dzu = LD16(g_depth + p);
+        const float4 dz = make_float4(__uint_as_float(dzu.x), __uint_as_float(dzu.y), __uint_as_float(dzu.z), __uint_as_float(dzu.w));
+        const uint4 df = LD16(g_diff + p);
+        const uint4 sp = LD16(g_spec + p);
+        const uint4 n0 = LD16(g_nrm + p);
+        const uint4 n1 = LD16(g_nrm + p + 2);
+        const uint4 e0 = LD16(g_emi + p);
+        const uint4 e1 = LD16(g_emi + p + 2);
+#undef LD16
         depth[0] = dz.x; depth[1] = dz.y; depth[2] = dz.z; depth[3] = dz.w;
         dfa[0] = df.x; dfa[1] = df.y; dfa[2] = df.z; dfa[3] = df.w; spa[0] = sp.x; spa[1] = sp.y; spa[2] = sp.z; spa[3] = sp.w;
         na[0] = n0.x; na[1] = n0.y; na[2] = n0.z; na[3] = n0.w; na[4] = n1.x; na[5] = n1.y; na[6] = n1.z; na[7] = n1.w;
@@ -803,7 +863,7 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
             o[2 * k + 1] = vr_float_to_half(rgb[2]);
         }
     }
-    if (inside) store_quad<PACKED>(out, out_index, o);
+    if (inside) store_quad<PACKED, NT>(out, out_index, o);
 }
 
 extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, const vr_light* lights,
@@ -860,7 +920,8 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         VR_HIP(hipMalloc(&ctx->d_macro_scratch, scratch_words * sizeof(uint32_t)));
         ctx->macro_scratch_words = scratch_words;
     }
-    VrKernelScope ks(ctx, VR_K_DEFERRED_TILED);
+    // two launches, each timed under its own id; the shading kernel's events are stamped by its dispatch like the streaming
+    // pass's, so its stop event serves as the next frame's geometry start hint (vr_terrain_prepare)
     if (packed) {
         const PartTables* pt = nullptr;
         int rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt);
@@ -868,19 +929,27 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (pt->num_owned > 0) {
-            hipLaunchKernelGGL(k_light_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                               gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch);
-            hipLaunchKernelGGL((k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), 0, ctx->stream, a,
-                               ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
-                               ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx);
+            { VrKernelScope kc(ctx, VR_K_LIGHT_CULL);
+              hipLaunchKernelGGL(k_light_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                                 gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch); }
+            VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
+            VR_LAUNCH_TIMED(ks, (k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), ctx->stream, a,
+                            ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
+                            ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx);
         }
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
-        hipLaunchKernelGGL(k_light_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                           gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch);
-        hipLaunchKernelGGL((k_deferred_tiled<false, VR_TILED_PXB>), dim3((unsigned)(tx * ty)), dim3(256), 0, ctx->stream, a, ctx->d_lights,
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
-                           (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
+        { VrKernelScope kc(ctx, VR_K_LIGHT_CULL);
+          hipLaunchKernelGGL(k_light_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
+                             gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch); }
+        VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
+        const bool nt = vr_raster_tile_shift(gb->w, gb->h) == 6;      // as in the streaming pass: large frames leave through streaming stores
+        if (nt) VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, true>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,
+                                gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
+                                (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
+        else VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, false>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,
+                             gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
+                             (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;

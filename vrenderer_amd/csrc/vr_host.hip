@@ -40,9 +40,10 @@ extern "C" VR_API int vr_context_create(int device, vr_context** out)
     c->h_srgb_thr[0] = 0.0f;
     for (int k = 1; k < 256; k++) c->h_srgb_thr[k] = (float)srgb_eotf(((double)k - 0.5) / 255.0);
     VR_HIP(hipMalloc(&c->d_srgb_lut, 256 * sizeof(float)));
-    VR_HIP(hipMalloc(&c->d_srgb_thr, 256 * sizeof(float)));
+    VR_HIP(hipMalloc(&c->d_srgb_thr, 257 * sizeof(float)));          // [256] = NaN: no x is >= it (readers that index thr[code + 1])
     VR_HIP(hipMemcpy(c->d_srgb_lut, c->h_srgb_lut, 256 * sizeof(float), hipMemcpyHostToDevice));
     VR_HIP(hipMemcpy(c->d_srgb_thr, c->h_srgb_thr, 256 * sizeof(float), hipMemcpyHostToDevice));
+    { const uint32_t nan_bits = 0x7fc00000u; VR_HIP(hipMemcpy(c->d_srgb_thr + 256, &nan_bits, sizeof(nan_bits), hipMemcpyHostToDevice)); }
     {   // start table for the device encoder: code of the smallest float in each bucket
         uint8_t tab[kEncTabSize];
         for (int b = 0; b < kEncTabSize; b++) {
@@ -204,7 +205,7 @@ extern "C" VR_API const char* vr_kernel_name(int id)
 {
     static const char* names[VR_K_COUNT] = { "k_select", "k_vertex", "k_setup", "k_clip", "k_scan", "k_fill", "k_raster",
                                               "k_deferred", "k_detile", "k_fill_u32 (clear)", "k_deferred_tiled", "k_node_heights (all levels)",
-                                              "k_tm_histogram", "k_tm_exposure", "k_tonemap", "k_detile_ldr" };
+                                              "k_tm_histogram", "k_tm_exposure", "k_tonemap", "k_detile_ldr", "k_raster (depth only)", "k_light_cull" };
     return (id >= 0 && id < VR_K_COUNT) ? names[id] : "?";
 }
 

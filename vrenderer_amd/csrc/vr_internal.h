@@ -186,6 +186,7 @@ struct GeoSet {
     uint32_t* d_node_ids = nullptr;      // select outputs
     vr_instance* d_instances = nullptr;
     uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
+    uint32_t* d_sel_scratch = nullptr;   // k_select: the frontiers' overflow beyond their LDS part and the selected keys (one workgroup's scratch)
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled
     uint4* d_recs = nullptr;             // per surviving triangle: its set-up record (kRecGroups x 16 B), then the clipper's (hard_cap * 4)
@@ -224,6 +225,7 @@ struct vr_terrain {
     float lod_ranges[VR_MAX_LODS];
     DevTex height, albedo;
     uint8_t* d_height = nullptr; uint8_t* d_albedo = nullptr;
+    uint64_t bytes_textures = 0, bytes_scratch = 0;     // vr_terrain_memory_bytes
     uint32_t extra_vert_cap = 0, hard_cap = 0;
     size_t bin_capacity = 0;
     GeoSet sets[kGeoSets];
@@ -253,7 +255,7 @@ struct vr_tonemap;
 vr_context* vr_tonemap_context(vr_tonemap* tm);
 // ---- cross-TU entry points ----------------------------------------------------------
 int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int texel_bytes,
-                          DevTex* out, uint8_t** out_mem);
+                          DevTex* out, uint8_t** out_mem, uint64_t* out_bytes = nullptr);
 int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream);
 int vr_terrain_pick_set(vr_terrain* t);
 // tables of (w, h, part); part == NULL is the whole frame as rank 0 of 1

@@ -308,8 +308,17 @@ __device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVer
 {
     TriSetup t = tri_setup(s0, s1, s2, a.mirrored, a.vx0, a.vy0, a.vx1, a.vy1, a.wireframe != 0);
     if (!t.visible) return ~0ull;
+    const int tx0 = t.x0 >> a.tile_shift, ty0 = t.y0 >> a.tile_shift, tx1 = t.x1 >> a.tile_shift, ty1 = t.y1 >> a.tile_shift;
+    if (a.world > 1) {
+        // A rank of an N-way split draws 1/N of the tiles but sets up all the geometry: a triangle that touches none of this
+        // rank's tiles needs neither a record (its plane set-up in double precision is most of this kernel) nor a bin.
+        bool mine = false;
+        for (int ty = ty0; ty <= ty1 && !mine; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) if (tile_owned(a, tx, ty)) { mine = true; break; }
+        if (!mine) return ~0ull;
+    }
     write_tri_rec(rec, t, s0, s1, s2);          // tri_setup has put the vertices into clockwise order
-    return pack_rect(t.x0 >> a.tile_shift, t.y0 >> a.tile_shift, t.x1 >> a.tile_shift, t.y1 >> a.tile_shift);
+    return pack_rect(tx0, ty0, tx1, ty1);
 }
 
 // Adds `r`'s triangle to the per-tile counters (FILL = false) or claims its bin slots and writes
@@ -500,54 +509,88 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 // k_scan: exclusive prefix sum of the per-tile counts (one workgroup)
 // ---------------------------------------------------------------------------------------
 // It also orders the tiles the tile pass will launch over (all of them, or this rank's `cand` list) by falling bin
-// length (buckets of powers of two; empty bins - the sky - last): workgroups are handed out in launch order, so the
+// length (eight classes; empty bins - the sky - last): workgroups are handed out in launch order, so the
 // expensive tiles start first and the cheap ones fill the tail of the launch (measured: -2.5 % on the 8K tile pass).
+// One workgroup, two barriers: every thread owns a contiguous chunk of the tile list; chunk sums and per-class tile
+// counts are scanned inside the waves with shuffles and across the sixteen waves through 144 words of LDS.
+// (Round 2's version - 1024 LDS atomics per round on a few histogram words and a twenty-barrier Hillis-Steele scan - took
+// 33 us alone; this one is bounded by its two dependent passes over the counts.)
+constexpr int kScanClasses = 8;
+__device__ __forceinline__ int scan_class(uint32_t cnt)
+{
+    if (cnt == 0u) return 7;
+    const int k = 31 - __clz((int)cnt);                  // floor(log2): >= 256 entries -> 0, 128.. -> 1, 64.. -> 2, 32.. -> 3, 16.. -> 4, 4.. -> 5, 1.. -> 6
+    return k >= 8 ? 0 : (k >= 4 ? 8 - k : (k >= 2 ? 5 : 6));
+}
 __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity,
                                                 const int32_t* __restrict__ cand, int n_cand, int32_t* __restrict__ order)
 {
-    __shared__ uint32_t partial[1024];
-    __shared__ uint32_t hist[33], start[33];
-    const int tid = threadIdx.x;
-    if (tid < 33) hist[tid] = 0u;
-    __syncthreads();
-    for (int c = tid; c < n_cand; c += 1024) {
-        const uint32_t cnt = tile_count[cand ? cand[c] : c];
-        atomicAdd(&hist[cnt ? __clz((int)cnt) : 32], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) { uint32_t run = 0; for (int k = 0; k < 33; k++) { start[k] = run; run += hist[k]; } }
-    __syncthreads();
-    for (int c = tid; c < n_cand; c += 1024) {
-        const int tile = cand ? cand[c] : c;
-        const uint32_t cnt = tile_count[tile];
-        order[atomicAdd(&start[cnt ? __clz((int)cnt) : 32], 1u)] = tile;
-    }
-    __syncthreads();                                      // every count has been read; they are consumed (zeroed) below
+    __shared__ uint32_t s_wsum[16];                       // per wave: sum of its threads' counts -> exclusive base
+    __shared__ uint32_t s_cls[kScanClasses * 16];         // per (class, wave): tiles of that class -> first slot in `order`
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // A rank's bins are the candidates' only (k_setup / k_fill count owned tiles alone): scan that list, not the frame.
-    const int n_scan = cand ? n_cand : n_tiles;
-    const int per = (n_scan + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, n_scan);
-    uint32_t s = 0;
-    for (int i = b; i < e; i++) s += tile_count[cand ? cand[i] : i];
-    partial[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? partial[tid - off] : 0u;
-        __syncthreads();
-        partial[tid] += v;
-        __syncthreads();
+    const int n = cand ? n_cand : n_tiles;
+    const int per = (n + 1023) / 1024;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    uint32_t s = 0, cc[kScanClasses];
+#pragma unroll
+    for (int c = 0; c < kScanClasses; c++) cc[c] = 0u;
+    for (int i = b; i < e; i++) {
+        const uint32_t cnt = tile_count[cand ? cand[i] : i];
+        s += cnt;
+        const int cl = scan_class(cnt);
+#pragma unroll
+        for (int c = 0; c < kScanClasses; c++) cc[c] += cl == c ? 1u : 0u;
     }
-    uint32_t run = partial[tid] - s;
+    // inclusive scans inside the wave
+    uint32_t incl = s, ci[kScanClasses];
+#pragma unroll
+    for (int c = 0; c < kScanClasses; c++) ci[c] = cc[c];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += v;
+#pragma unroll
+        for (int c = 0; c < kScanClasses; c++) { const uint32_t w = (uint32_t)__shfl_up((int)ci[c], d); if (lane >= d) ci[c] += w; }
+    }
+    if (lane == 63) {
+        s_wsum[wave] = incl;
+#pragma unroll
+        for (int c = 0; c < kScanClasses; c++) s_cls[c * 16 + wave] = ci[c];
+    }
+    __syncthreads();
+    if (wave == 0) {       // exclusive scans of the 16 wave sums and of the 128 (class-major) tile counts, two per lane
+        uint32_t v = lane < 16 ? s_wsum[lane] : 0u, run = v;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const uint32_t w = (uint32_t)__shfl_up((int)run, d); if (lane >= d) run += w; }
+        if (lane < 16) s_wsum[lane] = run - v;
+        if (lane == 15) {
+            counters[C_BINTOTAL] = run;
+            if (run > capacity) atomicOr(&counters[C_FLAGS], 2u);
+        }
+        const uint32_t a0 = s_cls[2 * lane], a1 = s_cls[2 * lane + 1];
+        uint32_t pr = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t w = (uint32_t)__shfl_up((int)pr, d); if (lane >= d) pr += w; }
+        s_cls[2 * lane] = pr - (a0 + a1); s_cls[2 * lane + 1] = pr - a1;
+    }
+    __syncthreads();
+    uint32_t run = s_wsum[wave] + (incl - s);
+    uint32_t slot[kScanClasses];
+#pragma unroll
+    for (int c = 0; c < kScanClasses; c++) slot[c] = s_cls[c * 16 + wave] + (ci[c] - cc[c]);
     // the counts are consumed here: zero them for the next frame (saves a memset per frame); the
     // rasteriser gets a bin's length from cursor - offset once k_fill has run
     for (int i = b; i < e; i++) {
         const int t = cand ? cand[i] : i;
-        tile_offset[t] = run; tile_cursor[t] = run; run += tile_count[t]; tile_count[t] = 0u;
-    }
-    if (tid == 1023) {
-        counters[C_BINTOTAL] = partial[1023];
-        if (partial[1023] > capacity) atomicOr(&counters[C_FLAGS], 2u);
+        const uint32_t cnt = tile_count[t];
+        tile_offset[t] = run; tile_cursor[t] = run; run += cnt; tile_count[t] = 0u;
+        const int cl = scan_class(cnt);
+        uint32_t pos = 0u;
+#pragma unroll
+        for (int c = 0; c < kScanClasses; c++) if (cl == c) { pos = slot[c]; slot[c] = pos + 1u; }
+        order[pos] = t;
     }
 }
 
@@ -641,16 +684,29 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     const Axis xa = tap_axis(w, ua), xb = tap_axis(w, ub), x0 = tap_axis(w, u0), y0 = tap_axis(h, v0), ya = tap_axis(h, va), yb = tap_axis(h, vb);
     const int r0 = __mul24(y0.i + 1, w + 2) + 1, ra = __mul24(ya.i + 1, w + 2) + 1, rb = __mul24(yb.i + 1, w + 2) + 1;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef VR_EXP_SAMEADDR   // timing experiment only (wrong image): every lane fetches texel 0 - what does the memory system cost?
+    const uint32_t amask = hm.w0 > 100000 ? ~0u : 0u;
+#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, ((q + (uint32_t)(i)) << 4) & amask, 0, 0)
+#else
 #define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, (q + (uint32_t)(i)) << 4, 0, 0)
+#endif
     const u32x4 e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
     const uint32_t c4 = c << 2;                                   // the decoded chain: 16 B per texel, levels at 4 x the byte offset
+#ifdef VR_EXP_SAMEADDR
+#define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, (((uint32_t)(i) << 4) + c4) & amask, 0, 0)
+#else
 #define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, ((uint32_t)(i) << 4) + c4, 0, 0)
+#endif
     u32x4 p00, p10, p01, p11;
     float cfx, cfy;
     if (SAME) {
         const int cx0 = vr_clampi(x0.i, 0, w - 1), cx1 = vr_clampi(x0.i + 1, 0, w - 1), cy0 = vr_clampi(y0.i, 0, h - 1), cy1 = vr_clampi(y0.i + 1, 0, h - 1);
         const int q0 = __mul24(cy0, w), q1 = __mul24(cy1, w);
+#ifdef VR_EXP_ALB1       // timing experiment only (wrong colours): one albedo fetch instead of four - how much of the pass is the L1?
+        p00 = LDC(q0 + cx0); p10 = p00; p01 = p00; p11 = p00; p11.x += (uint32_t)(q1 + cx1);
+#else
         p00 = LDC(q0 + cx0); p10 = LDC(q0 + cx1); p01 = LDC(q1 + cx0); p11 = LDC(q1 + cx1);
+#endif
         cfx = x0.f; cfy = y0.f;
     } else {
         const BilinearSetup s = vr_bilinear_setup(max(1, al.w0 >> lvl_c), max(1, al.h0 >> lvl_c), u, v);
@@ -679,14 +735,19 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
 // (only when a LOD fraction is non-zero) as a second batch.
 // Texels are fetched through buffer resources (rq: the quad tables, rc: the albedo chain): a fetch's address is one
 // 32-bit byte offset (1 VALU) instead of a 64-bit pointer sum (3), and an out-of-range offset reads 0 instead of faulting.
-template <bool SAME>
+// POW2: the world size is a power of two (known at compile time in the fast variant of the tile pass): "/ world_size" is one
+// multiplication, with no run-time choice between the two forms - six scalar branches per pixel otherwise.
+template <bool SAME, bool POW2>
 __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& hm, const DevTex& al, __amdgpu_buffer_rsrc_t rq,
                                              __amdgpu_buffer_rsrc_t rc, const float* __restrict__ thr, const uint8_t* __restrict__ enc,
                                              const uint32_t* __restrict__ qoff, const uint32_t* __restrict__ aoff, const Attr& p,
                                              uint32_t& diffuse, uint32_t& n01, uint32_t& n23)
 {
-    const float u = to_uv(a, p.wx), v = to_uv(a, p.wz);                                      // :12-13, :20-21
-    const float dudx = div_ws(a, p.dwxdx), dvdx = div_ws(a, p.dwzdx), dudy = div_ws(a, p.dwxdy), dvdy = div_ws(a, p.dwzdy);
+#define DIVWS(x) (POW2 ? (x) * a.inv_world_size : div_ws(a, (x)))
+    const float half_ws = a.world_size * 0.5f;
+    const float u = DIVWS(p.wx + half_ws), v = DIVWS(p.wz + half_ws);                        // :12-13, :20-21
+    const float dudx = DIVWS(p.dwxdx), dvdx = DIVWS(p.dwzdx), dudy = DIVWS(p.dwxdy), dvdy = DIVWS(p.dwzdy);
+#undef DIVWS
     const float lod_h = vr_lod_from_derivs(dudx, dvdx, dudy, dvdy, hm.w0, hm.h0);
     const LodSplit lh = vr_lod_split(hm.levels, lod_h);
     LodSplit lc = lh;                                            // same size and level count: the same LOD
@@ -698,7 +759,11 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     sample_level<SAME>(hm, al, rq, rc, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
+#ifdef VR_EXP_NOLEVEL1
+    if (hm.w0 > 100000) {
+#else
     if (__any(lh.f > 0.0f || lc.f > 0.0f)) {
+#endif
         // blending with a zero fraction returns the finer sample exactly, so one branch serves both textures
         const int l1h = min(lh.l0 + 1, hm.levels - 1), l1c = min(lc.l0 + 1, al.levels - 1);
         // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
@@ -718,8 +783,12 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     // normalize(): 1.0f / sqrtf(fma(nz, nz, fma(nx, nx, ny * ny))), length in [0.2, 1.43]
     const float inv = vr_rcp_exact(vr_sqrt_exact(__builtin_fmaf(nz, nz, __builtin_fmaf(nx, nx, ny * ny))));
     nx *= inv; ny *= inv; nz *= inv;
+#ifdef VR_EXP_NOENCODE
+    diffuse = (__float_as_uint(col[0]) >> 20) | ((__float_as_uint(col[1]) >> 20) << 8) | ((__float_as_uint(col[2]) >> 20) << 16) | 0xff000000u;
+#else
     diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
+#endif
     n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
     n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
 }
@@ -899,7 +968,13 @@ constexpr int kRT = VR_RASTER_THREADS, kRW = kRT / 64;
 #define VR_RASTER_WAVES_PER_EU kRW
 #endif
 
-template <bool WIRE, int TILE, bool SAME>
+// Variants of the tile pass's resolve (the coverage phase is the same in all of them):
+//   RM_FAST    the reference's case, with everything the host knows about it compiled in: heightmap and albedo of one size,
+//              a power-of-two world size, G-buffer planes within 4 GB of each other (one buffer resource), shaded;
+//   RM_DEPTH   depth only (the shadow map's pass): no record fetch, no texel fetch, one store per pixel;
+//   RM_GENERIC everything else, decided at run time.
+enum { RM_GENERIC = 0, RM_FAST = 1, RM_DEPTH = 2 };
+template <bool WIRE, int TILE, int MODE>
 __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
@@ -911,9 +986,16 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const)
 {
     __shared__ unsigned long long vis[TILE * TILE];
+#ifdef VR_EXP_GLOBAL_TABLES   // experiment: the small tables read from global memory, so that a 64-pixel tile's workgroup needs exactly 32 KB of LDS (5 per CU)
+    const uint8_t* __restrict__ enc = enc_g;
+    const float* __restrict__ thr = thr_g;
+    const uint32_t* __restrict__ s_qoff = hm.qoff;
+    const uint32_t* __restrict__ s_aoff = al.off;
+#else
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float thr[kThrTabSize];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef VR_LDS_PAD      // experiments only: extra LDS per workgroup = fewer workgroups per CU (occupancy sensitivity of the tile pass)
     __shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
@@ -923,12 +1005,14 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
+#ifndef VR_EXP_GLOBAL_TABLES
     if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
     for (int i = tid; i < (kEncTabSize + 3) / 4; i += kRT) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
-    const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
-    const int ox = txi * TILE, oy = tyi * TILE;
     if (tid < 256) thr[tid] = thr_g[tid];
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
+#endif
+    const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
+    const int ox = txi * TILE, oy = tyi * TILE;
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
     if (a.assume_cleared && ox + TILE <= a.w && oy + TILE <= a.h) {       // interior tile of a cleared target: one constant
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -1104,22 +1188,23 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     VR_PROF_MARK(5);
 
     // ---- resolve: shade each pixel's winner once ------------------
+    constexpr bool FAST = MODE == RM_FAST, DEPTH = MODE == RM_DEPTH, SAME = FAST;
+    const bool depth_only = DEPTH || (!FAST && a.depth_only != 0);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
-    // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K)
+    // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K;
+    // the host launches the fast variant only then)
     const uint64_t gb_span = (uint64_t)(reinterpret_cast<const char*>(g_emi + (size_t)a.w * a.h) - reinterpret_cast<const char*>(g_depth));
     const uint64_t od = (uint64_t)(reinterpret_cast<const char*>(g_diff) - reinterpret_cast<const char*>(g_depth));
     const uint64_t os = (uint64_t)(reinterpret_cast<const char*>(g_spec) - reinterpret_cast<const char*>(g_depth));
     const uint64_t on = (uint64_t)(reinterpret_cast<const char*>(g_nrm) - reinterpret_cast<const char*>(g_depth));
     const uint64_t oe = (uint64_t)(reinterpret_cast<const char*>(g_emi) - reinterpret_cast<const char*>(g_depth));
-    const bool gb_small = gb_span < (1ull << 32) && od < gb_span && os < gb_span && on < gb_span && oe < gb_span;
+    const bool gb_small = FAST || (gb_span < (1ull << 32) && od < gb_span && os < gb_span && on < gb_span && oe < gb_span);
     const int o_diff = (int)(uint32_t)od, o_spec = (int)(uint32_t)os, o_nrm = (int)(uint32_t)on, o_emi = (int)(uint32_t)oe;
     const __amdgpu_buffer_rsrc_t rgb = __builtin_amdgcn_make_buffer_rsrc((void*)g_depth, (short)0, (int)(uint32_t)gb_span, 0x00020000);
     // A lane owns a column of four pixels, the lanes of a wave are neighbouring columns: one texel fetch of the wave then
     // touches adjacent texels (8 lanes per 128-byte line where the terrain is minified) instead of every fourth one, as it
-    // did when a lane owned four pixels of a row.  The L1 is what this phase runs against - its tag look-ups were busy
-    // 63 % of the kernel's cycles plus 30 % stalled (TCP_TOTAL_CACHE_ACCESSES, TCP_PENDING_STALL_CYCLES), 22 look-ups per
-    // fetch instruction - not the vector pipes.
+    // did when a lane owned four pixels of a row.
     // Every pixel leaves through its stores as soon as it is shaded (nothing is kept for the end of the column): a wave's
     // store covers 64 (32) neighbouring pixels of a row, 256 contiguous bytes per 4-byte plane.
     // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
@@ -1129,62 +1214,69 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
     // The five planes of a vr_gbuffer are one allocation: one buffer resource, the plane as the scalar offset and one
     // 32-bit pixel offset per store instead of a 64-bit address per plane and pixel.
+    // The hot path is kept free of taken branches: everything the fast variant knows is a template parameter, the implicit
+    // LOD is computed with selects, and the two rare cases (a reciprocal outside the short sequence's range, a second mip
+    // level) sit behind wave-uniform branches that fall through when they do not apply.
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     constexpr int aux = TILE == 64 ? 2 : 0;               // nt
 #define ST1(ptr, v) do { if (TILE == 64) __builtin_nontemporal_store((v), (ptr)); else *(ptr) = (v); } while (0)
 #define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); \
                               else *reinterpret_cast<u2*>(ptr) = v_; } while (0)
+    const bool whole = ox + TILE <= a.w && oy + TILE <= a.h;      // (workgroup-uniform) no pixel of this tile lies outside the target
     for (int g = tid; g < TILE * TILE / 4; g += kRT) {
         const int lx = g % TILE, ly0 = (g / TILE) * 4;
         const int gx = ox + lx, gy0 = oy + ly0;
-        if (gy0 >= a.h || gx >= a.w) continue;
-        uint32_t prev = 0xffffffffu;
-        // the winner's planes (record groups 5..7) and this column's offset from their anchor
-        // (deliberately not initialised: the first covered pixel of a group always loads its record - prev matches no key)
-        float q0, qx, qy, nx0, nxx, nxy, nz0, nzx, nzy, fdx, fdy0;
+        if (!whole && (gy0 >= a.h || gx >= a.w)) continue;
         // the column's four visibility words ahead of the per-pixel control flow
         const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
-        uint32_t pix = (uint32_t)gy0 * (uint32_t)a.w + (uint32_t)gx;
+        uint32_t pix = (uint32_t)__umul24(gy0, a.w) + (uint32_t)gx;          // < 2^28: both factors below 2^14
+        // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD: pixel k + 1's record is requested before pixel
+        // k is shaded, so its round trip (entry -> record, a gather: every lane its own triangle) runs under pixel k's texel
+        // fetches instead of in front of pixel k + 1's.  A pixel's chain of dependent memory accesses - visibility word,
+        // record, finer level, coarser level - is what the resolve waits for (SQ_WAIT_ANY: half of the wave cycles), not the
+        // number of fetches: three albedo fetches fewer per level changed the pass by 1 % (profiles/r03_tile_pass_experiments.txt).
+        // (A record is fetched even when the lane's triangle did not change: a hit in the L1, and no divergent branch.)
+#define COVERED(k_) ((uint32_t)keys[k_] != 0xffffffffu && (whole || gy0 + (k_) < a.h) && !depth_only)
+#define FETCH_REC(k_, r5_, r6_, r7_) do { const uint4* __restrict__ rp_ = recs + rec_index(key_of((uint32_t)keys[k_]), hard_first, rec_hard_base) * kRecGroups; \
+                                          r5_ = rp_[5]; r6_ = rp_[6]; r7_ = rp_[7]; } while (0)
+        uint4 n5 = make_uint4(0, 0, 0, 0), n6 = n5, n7 = n5;                 // the NEXT pixel's record
+        if (COVERED(0)) FETCH_REC(0, n5, n6, n7);
 #pragma unroll
         for (int k = 0; k < 4; k++, pix += (uint32_t)a.w) {
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
-            if (gy0 + k >= a.h) continue;
+            const uint4 g5 = n5, g6 = n6, g7 = n7;                            // this pixel's record (requested one pixel ago)
+            if (k < 3) { if (COVERED(k + 1)) FETCH_REC(k + 1, n5, n6, n7); }
+            if (!whole && gy0 + k >= a.h) continue;
             const bool cov = low != 0xffffffffu;
             if (!cov && !a.assume_cleared) continue;               // keep what the target holds
             const uint32_t dep = (uint32_t)(key >> 32);
             uint32_t dif = 0, nn0 = 0, nn1 = 0;
-            if (cov && !a.depth_only) {
-                if (low != prev) {                                    // neighbours usually share the triangle
-                    const uint4* __restrict__ rp = recs + rec_index(key_of(low), hard_first, rec_hard_base) * kRecGroups;
-                    const uint4 g5 = rp[5], g6 = rp[6], g7 = rp[7];
-                    q0 = __uint_as_float(g5.x); qx = __uint_as_float(g5.y); qy = __uint_as_float(g5.z);
-                    nx0 = __uint_as_float(g6.x); nxx = __uint_as_float(g6.y); nxy = __uint_as_float(g6.z);
-                    nz0 = __uint_as_float(g7.x); nzx = __uint_as_float(g7.y); nzy = __uint_as_float(g7.z);
-                    fdx = (float)(gx - (int)(g5.w & 0xffffu)); fdy0 = (float)(gy0 - (int)(g5.w >> 16));
-                    prev = low;
-                }
+            if (cov && !depth_only) {
+                const float q0 = __uint_as_float(g5.x), qx = __uint_as_float(g5.y), qy = __uint_as_float(g5.z);
+                const float nx0 = __uint_as_float(g6.x), nxx = __uint_as_float(g6.y), nxy = __uint_as_float(g6.z);
+                const float nz0 = __uint_as_float(g7.x), nzx = __uint_as_float(g7.y), nzy = __uint_as_float(g7.z);
+                // this pixel's offset from the planes' anchor (exact: small integers)
+                const float fdx = (float)(gx - (int)(g5.w & 0xffffu)), fdy = (float)(gy0 + k - (int)(g5.w >> 16));
                 // perspective-correct world xz and its screen-space derivatives (oracle: interp)
                 Attr p;
                 {
-                    const float fdy = fdy0 + (float)k;              // exact: small integers
                     const float q = plane_at(q0, qx, qy, fdx, fdy);
-                    // 1.0f / q: q = the interpolated 1/w of a point in front of the near plane, far inside the safe range;
-                    // anything else (a wire pixel far off its triangle's plane) takes the general division
+                    // 1.0f / q: q = the interpolated 1/w of a point in front of the near plane, far inside the short sequence's
+                    // range; anything else (a wire pixel far off its triangle's plane) is redone with the general division
                     const float aq = fabsf(q);
-                    float r;
-                    if (__any(!(aq > 0x1p-60f && aq < 0x1p60f))) r = 1.0f / q;           // (wave-uniform, practically never taken)
-                    else r = vr_rcp_exact(q);
+                    float r = vr_rcp_exact(q);
+                    if (__builtin_expect(__any(!(aq > 0x1p-60f && aq < 0x1p60f)), 0)) r = 1.0f / q;     // (wave-uniform, practically never taken)
                     p.wx = plane_at(nx0, nxx, nxy, fdx, fdy) * r;
                     p.wz = plane_at(nz0, nzx, nzy, fdx, fdy) * r;
                     p.dwxdx = __builtin_fmaf(-p.wx, qx, nxx) * r; p.dwzdx = __builtin_fmaf(-p.wz, qx, nzx) * r;
                     p.dwxdy = __builtin_fmaf(-p.wx, qy, nxy) * r; p.dwzdy = __builtin_fmaf(-p.wz, qy, nzy) * r;
                 }
-                pixel_shader<SAME>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
+                pixel_shader<SAME, FAST>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
             if (gb_small) {
                 __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix << 2, 0, aux);
-                if (!a.depth_only) {
+                if (!depth_only) {
                     __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix << 2, o_diff, aux);
                     __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix << 2, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
@@ -1194,7 +1286,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
                 ST1(g_depth + p64, __uint_as_float(dep));
-                if (!a.depth_only) {
+                if (!depth_only) {
                     ST1(g_diff + p64, dif);
                     ST1(g_spec + p64, cov ? spec_const : 0u);
                     ST2(g_nrm + p64, nn0, nn1);
@@ -1205,6 +1297,8 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     }
 #undef ST1
 #undef ST2
+#undef COVERED
+#undef FETCH_REC
     VR_PROF_MARK(6);
 }
 
@@ -1401,12 +1495,21 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     else { VR_HIP(hipEventRecord(t->ev_raster_begin, s)); t->start_hint = t->ev_raster_begin; t->raster_begin_recorded = true; }
     hipEvent_t pass_stop = nullptr;
     if (grid > 0) {
-        VrKernelScope ks(ctx, VR_K_RASTER, s, true);
+        // a depth-only tile pass (the shadow map's) is timed under its own id: it is an order of magnitude shorter than the
+        // G-buffer pass and must not be averaged with it
+        VrKernelScope ks(ctx, rp->depth_only ? VR_K_RASTER_DEPTH : VR_K_RASTER, s, true);
         const int32_t* tiles = g.d_tile_order;            // this frame's tiles, longest bins first (k_scan)
-        // heightmap and albedo of one size (the reference's case): the albedo footprint shares the height taps' coordinates
+        // the fast variant: heightmap and albedo of one size (the albedo footprint shares the height taps' coordinates), a
+        // power-of-two world size, the five planes of the G-buffer within 4 GB (one buffer resource), filled and shaded
         const bool same = t->height.w0 == t->albedo.w0 && t->height.h0 == t->albedo.h0 && t->height.levels == t->albedo.levels;
-        auto kern = a.tile_shift == 5 ? (a.wireframe ? k_raster<true, 32, false> : (same ? k_raster<false, 32, true> : k_raster<false, 32, false>))
-                                      : (a.wireframe ? k_raster<true, 64, false> : (same ? k_raster<false, 64, true> : k_raster<false, 64, false>));
+        const uint64_t span = (uint64_t)((const char*)(gb->emissive + (size_t)gb->w * gb->h) - (const char*)gb->depth);
+        const bool one_rsrc = (const char*)gb->depth < (const char*)gb->diffuse && (const char*)gb->depth < (const char*)gb->specular
+                           && (const char*)gb->depth < (const char*)gb->normals && (const char*)gb->depth < (const char*)gb->emissive && span < (1ull << 32);
+        const bool fast = same && a.ws_pow2 && one_rsrc && !a.wireframe && !a.depth_only;
+        const bool depth = a.depth_only && !a.wireframe;
+        auto kern = a.tile_shift == 5
+            ? (a.wireframe ? k_raster<true, 32, RM_GENERIC> : fast ? k_raster<false, 32, RM_FAST> : depth ? k_raster<false, 32, RM_DEPTH> : k_raster<false, 32, RM_GENERIC>)
+            : (a.wireframe ? k_raster<true, 64, RM_GENERIC> : fast ? k_raster<false, 64, RM_FAST> : depth ? k_raster<false, 64, RM_DEPTH> : k_raster<false, 64, RM_GENERIC>);
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);

@@ -17,9 +17,15 @@
 #include <string.h>
 #include <stdlib.h>
 
-constexpr int kSelThreads = 1024;
-constexpr int kFrontierCap = 4096;
-constexpr int kSelectedCap = 4096;   // LDS capacity == the largest max_instances (more is an error anyway)
+// One workgroup of 256 threads with 16 KB of LDS: small enough to start on a CU that is full of tile-pass workgroups
+// (four of them leave 17 KB of LDS, sixteen wave slots and 128 registers per SIMD free).  Round 2's version - 1024
+// threads, 48 KB - had to wait for a CU to drain: 27 us alone, 90-130 us under the tile pass it shares the device with.
+constexpr int kSelThreads = 256;
+constexpr int kFrontierCap = 4096;   // entries per frontier buffer: the first kFrontLds in LDS, the rest in the set's global scratch
+constexpr int kFrontLds = 1536;
+constexpr int kSelectedCap = 4096;   // == the largest max_instances (more is an error anyway); the keys live in the global scratch
+constexpr int kRankChunk = 1024;     // the rank sort streams the keys through LDS this many at a time
+constexpr int kSelScratchWords = 2 * (kFrontierCap - kFrontLds) + kSelectedCap;
 
 struct SelectArgs {
     float cam[3];
@@ -97,14 +103,19 @@ __device__ __forceinline__ uint32_t node_id_of(const NodeGeom& g, int depth)
 
 __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* __restrict__ node_ids,
                                                         vr_instance* __restrict__ inst, uint32_t* __restrict__ counters,
-                                                        const float2* __restrict__ heights)
+                                                        const float2* __restrict__ heights, uint32_t* __restrict__ scratch)
 {
-    __shared__ uint32_t frontier[2][kFrontierCap];
-    __shared__ uint32_t selected[kSelectedCap];
+    __shared__ uint32_t frontier[2][kFrontLds];
+    __shared__ uint32_t chunk[kRankChunk];
     __shared__ uint32_t n_front[2], n_sel, overflow;
+    uint32_t* __restrict__ spill[2] = { scratch, scratch + (kFrontierCap - kFrontLds) };
+    uint32_t* __restrict__ selected = scratch + 2 * (kFrontierCap - kFrontLds);
+    // (the scratch is written and read by this one workgroup only, with a barrier in between: one CU, one L1)
+#define FR_GET(buf, i) ((i) < (uint32_t)kFrontLds ? frontier[buf][i] : spill[buf][(i) - (uint32_t)kFrontLds])
+#define FR_PUT(buf, i, v) do { if ((i) < (uint32_t)kFrontLds) frontier[buf][i] = (v); else spill[buf][(i) - (uint32_t)kFrontLds] = (v); } while (0)
     const int tid = threadIdx.x;
     const int L = a.num_lods;
-    if (tid < a.num_surfaces) frontier[0][tid] = (uint32_t)tid << kPathBits;      // every quadtree's root
+    if (tid < a.num_surfaces) frontier[0][tid] = (uint32_t)tid << kPathBits;      // every quadtree's root (at most 64)
     if (tid == 0) { n_front[0] = (uint32_t)a.num_surfaces; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
     __syncthreads();
 
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         const int depth = L - lod;
         const uint32_t n = n_front[cur];
         for (uint32_t i = tid; i < n; i += kSelThreads) {
-            const uint32_t entry = frontier[cur][i];
+            const uint32_t entry = FR_GET(cur, i);
             const uint32_t path = entry & ((1u << kPathBits) - 1u);
             const int surf = (int)(entry >> kPathBits);
             NodeGeom g = node_from_path(a, path, depth, surf);
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
                 uint32_t slot = atomicAdd(&n_front[cur ^ 1], 4u);
                 if (slot + 4u <= (uint32_t)kFrontierCap) {
 #pragma unroll
-                    for (uint32_t c = 0; c < 4u; c++) frontier[cur ^ 1][slot + c] = ((uint32_t)surf << kPathBits) | (path << 2) | c;
+                    for (uint32_t c = 0; c < 4u; c++) FR_PUT(cur ^ 1, slot + c, ((uint32_t)surf << kPathBits) | (path << 2) | c);
                 } else overflow = 1u;
             }
         }
@@ -152,34 +163,56 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         cur ^= 1;
         __syncthreads();
     }
+#undef FR_GET
+#undef FR_PUT
 
-    // Depth-first order = ascending left-aligned path.  Keys are unique, so a node's
-    // rank is the number of smaller keys (LDS broadcast reads, no barriers).
+    // Depth-first order = ascending left-aligned path.  Keys are unique, so a node's rank is the number of smaller
+    // keys: the keys stream through LDS a chunk at a time and every thread counts for the (up to 16) keys it owns
+    // (LDS broadcast reads).
     uint32_t total = n_sel;
     if (total > (uint32_t)kSelectedCap) total = kSelectedCap;
     const uint32_t limit = min(total, (uint32_t)a.max_instances);
-    for (uint32_t i = tid; i < total; i += kSelThreads) {
-        uint32_t key = selected[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < total; j++) rank += selected[j] < key ? 1u : 0u;
-        if (rank >= limit) continue;
-        int depth = (int)(key & 15u);
-        const int surf = (int)(key >> 26);
-        uint32_t path = ((key >> 4) & ((1u << kPathBits) - 1u)) >> (2 * (L - depth));
+    constexpr int kOwn = kSelectedCap / kSelThreads;
+    const int own_n = (int)((total + kSelThreads - 1) / kSelThreads);        // keys per thread that exist at all (uniform; 2 for ~300 nodes)
+    uint32_t key[kOwn], rank[kOwn];
+#pragma unroll
+    for (int o = 0; o < kOwn; o++) { const uint32_t i = (uint32_t)tid + (uint32_t)o * kSelThreads; key[o] = i < total ? selected[i] : 0xffffffffu; rank[o] = 0u; }
+    for (uint32_t c0 = 0; c0 < total; c0 += kRankChunk) {
+        const uint32_t m = min(total - c0, (uint32_t)kRankChunk);
+        __syncthreads();
+        for (uint32_t j = tid; j < m; j += kSelThreads) chunk[j] = selected[c0 + j];
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < kOwn; o++) {
+            if (o >= own_n) break;                                            // (uniform)
+            uint32_t r = 0u;
+            const uint32_t ko = key[o];
+            for (uint32_t j = 0; j < m; j++) r += chunk[j] < ko ? 1u : 0u;
+            rank[o] += r;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < kOwn; o++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)o * kSelThreads;
+        if (i >= total || rank[o] >= limit) continue;
+        const uint32_t k = key[o];
+        int depth = (int)(k & 15u);
+        const int surf = (int)(k >> 26);
+        uint32_t path = ((k >> 4) & ((1u << kPathBits) - 1u)) >> (2 * (L - depth));
         NodeGeom g = node_from_path(a, path, depth, surf);
         const uint32_t id = (uint32_t)surf * a.nodes_per_tree + node_id_of(g, depth);
-        node_ids[rank] = id;
+        node_ids[rank[o]] = id;
         float py = a.loc[1], ey = 0.0f;
         if (a.height_loaded) { const float2 hy = heights[id]; py = hy.x; ey = hy.y; }
         // scaling(extents) * translation(position) -> float3x4 rows (TerrainPass.cpp:245-253)
-        vr_instance o;
-        o.padding = 0u; o.first_geometry_instance_index = 0u; o.first_geometry_index = 0u; o.num_geometries = 1u;
+        vr_instance ins;
+        ins.padding = 0u; ins.first_geometry_instance_index = 0u; ins.first_geometry_index = 0u; ins.num_geometries = 1u;
 #pragma unroll
-        for (int k = 0; k < 12; k++) { o.transform[k] = 0.0f; o.prev_transform[k] = 0.0f; }
-        o.transform[0] = g.ex; o.transform[3] = g.px;
-        o.transform[5] = ey; o.transform[7] = py;
-        o.transform[10] = g.ez; o.transform[11] = g.pz;
-        inst[rank] = o;
+        for (int q = 0; q < 12; q++) { ins.transform[q] = 0.0f; ins.prev_transform[q] = 0.0f; }
+        ins.transform[0] = g.ex; ins.transform[3] = g.px;
+        ins.transform[5] = ey; ins.transform[7] = py;
+        ins.transform[10] = g.ez; ins.transform[11] = g.pz;
+        inst[rank[o]] = ins;
     }
     if (tid == 0) {
         counters[0] = limit;
@@ -204,7 +237,7 @@ int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_he
     a.nodes_per_tree = (uint32_t)((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
     VrKernelScope ks(t->ctx, VR_K_SELECT, stream);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(kSelThreads), 0, stream, a, g.d_node_ids, g.d_instances, g.d_counters,
-                       (const float2*)t->d_node_heights);
+                       (const float2*)t->d_node_heights, g.d_sel_scratch);
     VR_HIP(hipGetLastError());
     g.have_selection = true;
     return VR_OK;
@@ -439,17 +472,19 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
     t->num_lods = (VR_MAX_LODS - 1) < l2 ? (VR_MAX_LODS - 1) : l2;
     t->texel_size[0] = (float)hm_w / params->world_size; t->texel_size[1] = (float)hm_h / params->world_size;   // QuadTree.cpp:29
     int rc;
-    if ((rc = vr_tex_upload_and_mip(ctx, height_r8, hm_w, hm_h, 1, &t->height, &t->d_height))) return rc;
-    if ((rc = vr_tex_upload_and_mip(ctx, albedo, al_w, al_h, 4, &t->albedo, &t->d_albedo))) return rc;
+    if ((rc = vr_tex_upload_and_mip(ctx, height_r8, hm_w, hm_h, 1, &t->height, &t->d_height, &t->bytes_textures))) return rc;
+    if ((rc = vr_tex_upload_and_mip(ctx, albedo, al_w, al_h, 4, &t->albedo, &t->d_albedo, &t->bytes_textures))) return rc;
     const size_t mi = (size_t)params->max_instances;
     t->extra_vert_cap = 1u << 16; t->hard_cap = 1u << 15;
 #define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
-        vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } } while (0)
+        vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } \
+        t->bytes_scratch += (uint64_t)(bytes); } while (0)
     t->bin_capacity = (size_t)16 << 20;
     for (GeoSet& g : t->sets) {
         VR_ALLOC(g.d_node_ids, mi * sizeof(uint32_t));
         VR_ALLOC(g.d_instances, mi * sizeof(vr_instance));
         VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
+        VR_ALLOC(g.d_sel_scratch, kSelScratchWords * sizeof(uint32_t));
         VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
         VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
         VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * kRecGroups * sizeof(uint4));
@@ -494,7 +529,7 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
         if (g.ev_sel_read) (void)hipEventDestroy(g.ev_sel_read);
-        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_verts);
+        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_sel_scratch); (void)hipFree(g.d_verts);
         (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
         (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
     }
@@ -627,5 +662,19 @@ extern "C" VR_API int vr_debug_download_vertices(vr_terrain* t, uint32_t first, 
         out[i * 6 + 0] = v[i].cx; out[i * 6 + 1] = v[i].cy; out[i * 6 + 2] = v[i].cz; out[i * 6 + 3] = v[i].cw;
         out[i * 6 + 4] = v[i].wx; out[i * 6 + 5] = v[i].wz;
     }
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_terrain_memory_bytes(const vr_terrain* t, uint64_t out[4])
+{
+    VR_REQUIRE(t && out, "NULL argument");
+    uint64_t tiles = 0;
+    for (const GeoSet& g : t->sets) tiles += (uint64_t)g.scratch_tiles * 4u * sizeof(uint32_t);
+    uint64_t heights = 0;
+    if (t->d_node_heights) {
+        const uint64_t nodes = ((((uint64_t)1 << (2 * (t->num_lods + 1))) - 1) / 3);
+        heights = nodes * (uint64_t)(t->surfaces_per_side * t->surfaces_per_side) * sizeof(float2) + (t->d_minmax ? nodes * sizeof(uchar2) : 0);
+    }
+    out[0] = t->bytes_textures; out[1] = t->bytes_scratch + tiles; out[2] = heights; out[3] = out[0] + out[1] + out[2];
     return VR_OK;
 }

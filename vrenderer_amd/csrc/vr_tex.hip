@@ -69,9 +69,12 @@ __global__ void k_decode_rgbf(const uint32_t* __restrict__ src, size_t n, const 
     }
 }
 
-int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int tb, DevTex* out, uint8_t** out_mem)
+int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, int tb, DevTex* out, uint8_t** out_mem, uint64_t* out_bytes)
 {
     VR_REQUIRE(host && w > 0 && h > 0 && w <= 16384 && h <= 16384, "bad texture");
+    // The tile pass reads DECODED copies (16 B per heightmap footprint and per albedo texel) through 32-bit byte offsets:
+    // a chain and its decoded tables must stay below 2 GB, which 8192 x 8192 texels (2^26) still do and more do not.
+    VR_REQUIRE((size_t)w * (size_t)h <= ((size_t)1 << 26), "textures above 2^26 texels (8192 x 8192) are not supported (decoded tables are addressed with 32-bit offsets)");
     int levels = 1; { int m = w > h ? w : h; while (m > 1) { m >>= 1; levels++; } }
     VR_REQUIRE(levels <= kMaxLevels, "too many mip levels");
     uint32_t off[kMaxLevels] = { 0 };
@@ -103,6 +106,7 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
     VR_REQUIRE(total < ((size_t)1 << 31), "texture too large");        // texels are addressed with 32-bit byte offsets
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
+    if (out_bytes) *out_bytes += total;
     hipStream_t s = ctx->stream;
     // on any failure below: wait for the copies that read this function's stack arrays, free, report
 #define VR_TEX_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipStreamSynchronize(s); (void)hipFree(mem); \

@@ -45,13 +45,14 @@ __device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, floa
     float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
     float r2x = __builtin_fmaf(ax, ax, ay * ay), r2y = __builtin_fmaf(bx, bx, by * by);      // fused sums of squares (oracle: lod_from_derivs)
     float r2 = r2x > r2y ? r2x : r2y;
-    if (!(r2 > 1.0f)) return 0.0f;
+    // (selects, not branches: the dozen instructions below cost less than two divergent branches around them)
     uint32_t bits = __float_as_uint(r2);
     int e = (int)((bits >> 23) & 255u) - 127;
-    if (e >= 128) return 64.0f;
     float tt = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
     float p = tt * __builtin_fmaf(tt, __builtin_fmaf(tt, 0.1563861f, -0.57725066f), 1.4208646f);
-    return 0.5f * ((float)e + p);
+    float lod = 0.5f * ((float)e + p);
+    lod = e >= 128 ? 64.0f : lod;                 // inf / NaN -> coarsest
+    return r2 > 1.0f ? lod : 0.0f;                // magnified (and NaN): level 0
 }
 
 // linear -> sRGB8: number of thresholds <= x (thr[0] = 0): round-to-nearest OETF.

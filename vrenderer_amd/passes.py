@@ -381,6 +381,12 @@ class TerrainPass:
         keys = ("nodes", "flags", "clip_subtris", "clip_verts", "clipped_tris", "bin_entries", "max_bin", "nonempty_bins")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def memory_bytes(self):
+        """Device memory this terrain holds: dict(textures, scratch, node_heights, total) in bytes."""
+        out = (C.c_uint64 * 4)()
+        check(self.ctx.lib.vr_terrain_memory_bytes(self.handle, out), "vr_terrain_memory_bytes")
+        return dict(zip(("textures", "scratch", "node_heights", "total"), [int(v) for v in out]))
+
     def download_vertices(self, first_instance, num_instances=1):
         """main_vs outputs of the last Render for whole instances: (n, 1089, 6) floats = clip xyzw + world xz (test helper)."""
         import numpy as np
