@@ -234,11 +234,11 @@ static float lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int
 {
     float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
     float r2x = fmaf(ax, ax, ay*ay), r2y = fmaf(bx, bx, by*by);
-    float r2 = r2x > r2y ? r2x : r2y;
-    if (!(r2 > 1.0f)) return 0.0f;
+    float r2 = fmaxf(r2x, r2y);                                   /* rho^2; IEEE maxNum: a NaN operand loses */
+    /* 0.5 * log2(r2) from the bits, for every input: magnified footprints (r2 <= 1) give a value <= 0 and an
+     * infinite one gives 64; the sampler clamps the result to [0, last level] (tex_trilinear) either way. */
     uint32_t bits = f2u(r2);
     int e = (int)((bits >> 23) & 255u) - 127;
-    if (e >= 128) return 64.0f;                                   /* inf/nan -> coarsest */
     float t = u2f((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
     float p = t * fmaf(t, fmaf(t, 0.1563861f, -0.57725066f), 1.4208646f);
     return 0.5f * ((float)e + p);

@@ -14,10 +14,12 @@ hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
 tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
 rt = vr.RenderTargets(ctx).Init(W, H)
 lib = capi.load_library()
-names = ["init", "fetch records", "tiny sweeps", "row sweeps", "big sweeps", "barrier wait", "resolve"]
+names = ["init", "fetch records", "tiny sweeps", "row sweeps", "big sweeps", "barrier wait", "(unused)", "(counts)",
+         "res: loop head + vis + record prefetch", "res: interp (waits for the record)", "res: uv, LOD, addresses, issue level 0", "res: wait for level 0", "res: filter level 0",
+         "res: level 1 (if any)", "res: normal + encodes", "res: stores"]
 def run(name, view, **kw):
     rp = vr.default_render_params(400.0, **kw)
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     tp.Render(view, view, rt, rp); ctx.synchronize()
     lib.vr_debug_raster_prof(buf, 1)
     ctx.timing_enable(True)
@@ -26,9 +28,10 @@ def run(name, view, **kw):
     ctx.synchronize()
     t = ctx.timing_collect(); ctx.timing_enable(False)
     lib.vr_debug_raster_prof(buf, 1)
-    tot = sum(buf[:7])
-    print(name, "k_raster %.1f us" % (t["k_raster"][0] / t["k_raster"][1] * 1e3),
-          {n: "%.1f%%" % (100.0 * buf[i] / tot) for i, n in enumerate(names)},
+    tot = sum(buf[:7]) + sum(buf[8:16])
+    kr = t.get("k_raster") or t.get("k_raster (depth only)")
+    print(name, "k_raster %.1f us" % (kr[0] / kr[1] * 1e3),
+          {n: "%.1f%%" % (100.0 * buf[i] / tot) for i, n in enumerate(names) if i != 7 and buf[i]},
           "wave-cycles/launch %.3g" % (tot / N),
           "triangles per launch: tiny %d, row %d, big %d" % ((buf[7] & 0xfffff) // N, ((buf[7] >> 20) & 0xfffff) // N, (buf[7] >> 40) // N), flush=True)
 for i in (30, 90):

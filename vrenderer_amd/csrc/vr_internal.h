@@ -68,6 +68,15 @@ struct DevTex {
     // SRGBA8 textures only: the chain decoded to linear floats, one float4 per texel (r, g, b, 0); level l starts at byte
     // 4 * off[l].  An albedo texel is then one aligned 16-byte load with nothing to extract or look up, at (index << 4).
     const float* rgbf;
+    // Both kinds, for the tile pass's fast variant (heightmap and albedo of one size): per level a (w+3) x (h+3) table of
+    // 16-byte entries - R8: the footprint (t00, t10 - t00, t01, t11 - t01) whose floor is (ix-1, iy-1); SRGBA8: the decoded
+    // texel (r, g, b, 0) at (ix-1, iy-1) - clamp-addressed, so that a bilinear footprint needs no clamp: texel (x, y),
+    // x in [-1, w], y in [-1, h], is entry (x+1, y+1) and its right / lower neighbours are +16 / +row bytes.  Textures of
+    // one size get identical layouts, so ONE set of byte offsets addresses the height taps and the albedo footprint.
+    // fast_lv[l] = { byte offset of entry (1, 1), row bytes, (float)w, (float)h } (what a pixel needs of level l).
+    const float4* fast;
+    const uint4* fast_lv;
+    uint32_t fast_bytes, pad2;
 };
 
 // Per-light constants the deferred kernel reads (host precomputes the half-angle terms).
@@ -268,29 +277,26 @@ __device__ __forceinline__ float vr_max(float a, float b) { return a > b ? a : b
 __device__ __forceinline__ float vr_min(float a, float b) { return a < b ? a : b; }
 // x clamped to [lo, hi] in one instruction (v_med3_f32); x must not be NaN
 __device__ __forceinline__ float vr_clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-// 1 / d and sqrt(x), correctly rounded, for operands well inside the normal range (2^-60 < |d|, x < 2^60): the compiler's
-// own IEEE sequences without the range scaling (v_div_scale / v_div_fixup, the 2^32 pre-scale of small roots) that
-// only matters outside it; results are bit-identical to 1.0f / d and sqrtf(x) there (vr_debug_fastmath_check sweeps
-// every float of the range).  Saves 4 and 9 instructions per call in the tile pass's pixel shader.
+// 1 / d and sqrt(x), correctly rounded, for operands well inside the normal range (2^-60 < |d|, x < 2^60): short sequences
+// found by exhaustive search (tools/micro/exact_math.hip, profiles/r03_exact_math_search.txt: every float of the range
+// compared with 1.0f / d and sqrtf(x) on the device; the product's copies are swept again by vr_debug_fastmath_check).
+//   reciprocal : v_rcp_f32 (1 ulp) + ONE Newton step with an exact fma residual      (the compiler's IEEE division: 10 instructions)
+//   square root: v_rsq_f32 + the compiler's own refinement without the range scaling (no compare / select)
 __device__ __forceinline__ float vr_rcp_exact(float d)
 {
-    float r = __builtin_amdgcn_rcpf(d);
+    const float r = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = r;                                         // 1 * r
-    float rem = __builtin_fmaf(-d, q, 1.0f);
-    q = __builtin_fmaf(rem, r, q);
-    rem = __builtin_fmaf(-d, q, 1.0f);
-    return __builtin_fmaf(rem, r, q);
+    return __builtin_fmaf(e, r, r);
 }
 __device__ __forceinline__ float vr_sqrt_exact(float x)
 {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
-    float r = vp <= 0.0f ? dn : s;
-    r = vs > 0.0f ? up : r;
-    return r;
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r, h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    s = __builtin_fmaf(s, e, s);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
 }
 __device__ __forceinline__ float vr_saturate(float x) { return vr_min(vr_max(x, 0.0f), 1.0f); }
 __device__ __forceinline__ float vr_dot3(float ax, float ay, float az, float bx, float by, float bz)

@@ -793,6 +793,146 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
 }
 
+// Phase clocks for experiments (tools/build_variant.py prof -DVR_RASTER_PROFILE); not in the product build.
+#ifdef VR_RASTER_PROFILE
+constexpr int kProfBlocks = 16384;
+constexpr int kProfSlots = 16;
+__device__ unsigned long long g_raster_prof[kProfBlocks * kProfSlots];
+// every wave's lane 0 adds its phase time to its block's slot (LDS-free, 4 waves per address)
+#define VR_PROF_MARK(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                                 atomicAdd(&g_raster_prof[blockIdx.x * kProfSlots + (i)], now_ - prof_t_); prof_t_ = __builtin_readcyclecounter(); } } while (0)
+#define VR_PROF_BEGIN unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define VR_PROF_PARAM , unsigned long long& prof_t_
+#define VR_PROF_ARG , prof_t_
+#define VR_PROF_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define VR_PROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) atomicAdd(&g_raster_prof[blockIdx.x * kProfSlots + (i)], (unsigned long long)(v)); } while (0)
+extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[16], int reset)
+{
+    static unsigned long long host[kProfBlocks * kProfSlots];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_raster_prof), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < kProfSlots; i++) out[i] = 0;
+    for (int b = 0; b < kProfBlocks; b++) for (int i = 0; i < kProfSlots; i++) out[i] += host[b * kProfSlots + i];
+    if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_prof), host, sizeof(host)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define VR_PROF_MARK(i) do { } while (0)
+#define VR_PROF_BEGIN do { } while (0)
+#define VR_PROF_PARAM
+#define VR_PROF_ARG
+#define VR_PROF_DRAIN do { } while (0)
+#define VR_PROF_ADD(i, v) do { } while (0)
+#endif
+
+// ---- the fast variant's pixel shader -------------------------------------------------------------------------------
+// Same arithmetic as pixel_shader<true, true> (bit for bit), arranged for what this part's vector pipes issue quickly
+// (tools/micro/valu_cost.hip, profiles/r03_valu_issue_costs.txt: at four waves per SIMD a v_mul / v_add / v_sub / v_fmac /
+// v_and / v_add_u32 costs ~1.2 cycles, a three-operand v_fma 2, and conversions, v_floor, v_med3 / min / max, shifts,
+// 24-bit mads, compares and selects ~3.2 - with two wait states between a compare and the select that reads it):
+//   - heights and albedo are read from the clamp-padded tables of DevTex::fast: one set of byte offsets serves the four
+//     height taps and the albedo footprint, built from three row products and fast adds; no clamp, no shift - an index
+//     is scaled by 16 as a FLOAT (exact) before its conversion, right / lower neighbours are immediate offsets;
+//   - what a pixel needs of a mip level (table offset, row bytes, float sizes) is one 16-byte LDS read;
+//   - the implicit LOD has no compare / select (oracle: lod_from_derivs), its clamp is one v_med3;
+//   - no range check in front of the short reciprocal: a pixel inside its triangle interpolates 1/w between its vertices'.
+__device__ __forceinline__ uint32_t srgb_encode_nonneg(float x, const float* __restrict__ thr, const uint8_t* __restrict__ tab)
+{
+    // vr_srgb_encode_fast for x in [0, 1] (a bilinear blend of decoded texels): no sign / NaN case, no upper clamp
+    const int b = max((int)(__float_as_uint(x) >> 16) - kEncTabBase, 0);
+    const uint32_t g = tab[b];
+    return g + (x >= thr[g + 1u] ? 1u : 0u);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct FastTaps { u32x4 e0, e1, e2, e3, p00, p10, p01, p11; float fxa, fxb, fx0, fy0, fya, fyb; };
+
+// One axis: texel-space coordinate -> fraction and the clamped floor, scaled by `scale` (16 for columns: a byte offset;
+// 1 for rows) while it is still a float (exact: |floor| <= 16385).
+#define FAST_AXIS(f_, i_, t_, n_, scale_) do { const float x_ = __builtin_fmaf((t_), (n_), -0.5f); const float xf_ = floorf(x_); (f_) = x_ - xf_; \
+                                                (i_) = (int)(vr_clampf(xf_, -1.0f, (n_)) * (scale_)); } while (0)
+
+__device__ __forceinline__ FastTaps issue_level_fast(__amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc, const uint4* __restrict__ s_lv, int lvl16,
+                                                     float ua, float ub, float va, float vb, float u0, float v0)
+{
+    FastTaps t;
+    const uint4 L = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(s_lv) + lvl16);     // { offset of entry (1, 1), row bytes, (float)w, (float)h }
+    const float wf = __uint_as_float(L.z), hf = __uint_as_float(L.w);
+    int xa, xb, x0, y0, ya, yb;
+    FAST_AXIS(t.fxa, xa, ua, wf, 16.0f); FAST_AXIS(t.fxb, xb, ub, wf, 16.0f); FAST_AXIS(t.fx0, x0, u0, wf, 16.0f);
+    FAST_AXIS(t.fy0, y0, v0, hf, 1.0f); FAST_AXIS(t.fya, ya, va, hf, 1.0f); FAST_AXIS(t.fyb, yb, vb, hf, 1.0f);
+    const uint32_t row0 = L.x + (uint32_t)__mul24(y0, (int)L.y), rowa = L.x + (uint32_t)__mul24(ya, (int)L.y), rowb = L.x + (uint32_t)__mul24(yb, (int)L.y);
+#define LD(r_, o_) __builtin_amdgcn_raw_buffer_load_b128((r_), (o_), 0, 0)
+    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0);
+    const uint32_t a00 = row0 + (uint32_t)x0, a01 = a00 + L.y;
+    t.p00 = LD(rc, a00); t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u);
+#undef LD
+    return t;
+}
+
+__device__ __forceinline__ void filter_level_fast(const FastTaps& t, float hgt[4], float col[3])
+{
+#define QF(e, fx, fy) ({ const float top_ = __builtin_fmaf(__uint_as_float((e).y), (fx), __uint_as_float((e).x)), \
+                                     bot_ = __builtin_fmaf(__uint_as_float((e).w), (fx), __uint_as_float((e).z)); \
+                         __builtin_fmaf(bot_ - top_, (fy), top_); })
+    hgt[0] = QF(t.e0, t.fxa, t.fy0); hgt[1] = QF(t.e1, t.fxb, t.fy0); hgt[2] = QF(t.e2, t.fx0, t.fya); hgt[3] = QF(t.e3, t.fx0, t.fyb);
+#undef QF
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t00 = __uint_as_float(t.p00[k]), t10 = __uint_as_float(t.p10[k]), t01 = __uint_as_float(t.p01[k]), t11 = __uint_as_float(t.p11[k]);
+        const float top = __builtin_fmaf(t10 - t00, t.fx0, t00), bot = __builtin_fmaf(t11 - t01, t.fx0, t01);
+        col[k] = __builtin_fmaf(bot - top, t.fy0, top);
+    }
+}
+
+__device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f, float h0f, float max_level, __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc,
+                                                  const float* __restrict__ thr, const uint8_t* __restrict__ enc, const uint4* __restrict__ s_lv, const Attr& p,
+                                                  uint32_t& diffuse, uint32_t& n01, uint32_t& n23 VR_PROF_PARAM)
+{
+    const float half_ws = a.world_size * 0.5f, iws = a.inv_world_size;
+    const float u = (p.wx + half_ws) * iws, v = (p.wz + half_ws) * iws;                       // :12-13, :20-21 (power-of-two world size)
+    const float lod = vr_lod_from_derivs_f(p.dwxdx * iws, p.dwzdx * iws, p.dwxdy * iws, p.dwzdy * iws, w0f, h0f);
+    const float lc = vr_clampf(lod, 0.0f, max_level);            // == the sampler's clamp (vr_lod_split): lod is never NaN
+    const float lf = floorf(lc), frac = lc - lf;
+    const int l16 = (int)(lf * 16.0f);                           // the level as a byte offset into the LDS level table
+    const float offset = 0.1f;                                                              // :59
+    const float ua = u + offset, ub = u + (-offset), va = v + offset, vb = v + (-offset);
+    float hgt[4], col[3];
+    {
+        const FastTaps t0 = issue_level_fast(rq, rc, s_lv, l16, ua, ub, va, vb, u, v);
+        VR_PROF_MARK(10);
+        VR_PROF_DRAIN;
+        VR_PROF_MARK(11);
+        filter_level_fast(t0, hgt, col);
+        VR_PROF_MARK(12);
+    }
+    // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
+    // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
+    if (__any(frac > 0.0f)) {
+        const int l16b = (int)(fminf(lf + 1.0f, max_level) * 16.0f);
+        // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
+        float xa = ua, xb = ub, ya = va, yb = vb, x0 = u, y0 = v;
+        asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ya), "+v"(yb), "+v"(x0), "+v"(y0));
+        float g[4], cb[3];
+        const FastTaps t1 = issue_level_fast(rq, rc, s_lv, l16b, xa, xb, ya, yb, x0, y0);
+        filter_level_fast(t1, g, cb);
+        // fma(b - a, f, a): with f == 0 this is a exactly (b - a is finite), as the oracle's "f > 0" branch leaves it
+#pragma unroll
+        for (int k = 0; k < 4; k++) hgt[k] = __builtin_fmaf(g[k] - hgt[k], frac, hgt[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) col[k] = __builtin_fmaf(cb[k] - col[k], frac, col[k]);
+    }
+    VR_PROF_MARK(13);
+    const float hDx = hgt[0] - hgt[1], hDy = hgt[2] - hgt[3];                                // :60-61
+    float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
+    const float inv = vr_rcp_exact(vr_sqrt_exact(__builtin_fmaf(nz, nz, __builtin_fmaf(nx, nx, ny * ny))));
+    nx *= inv; ny *= inv; nz *= inv;
+    diffuse = srgb_encode_nonneg(col[0], thr, enc) | (srgb_encode_nonneg(col[1], thr, enc) << 8) | (srgb_encode_nonneg(col[2], thr, enc) << 16)
+            | 0xff000000u;                                                                  // :68, :73-75
+    n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
+    n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
+    VR_PROF_MARK(14);
+}
+
 // Low half of a visibility-buffer word: ~(key + 1), so a later bin entry (larger key) gives a SMALLER word and
 // wins ties at equal depth (ds_min), and no entry - not even key 0, the first triangle of the first node -
 // collides with 0xffffffff, the "nothing drawn" value.
@@ -933,30 +1073,6 @@ __device__ __noinline__ void wire_edge(unsigned long long* __restrict__ vis, int
     }
 }
 
-// Phase clocks for experiments (tools/build_variant.py prof -DVR_RASTER_PROFILE); not in the product build.
-#ifdef VR_RASTER_PROFILE
-constexpr int kProfBlocks = 16384;
-__device__ unsigned long long g_raster_prof[kProfBlocks * 8];
-// every wave's lane 0 adds its phase time to its block's slot (LDS-free, 4 waves per address)
-#define VR_PROF_MARK(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-                                 atomicAdd(&g_raster_prof[blockIdx.x * 8 + (i)], now_ - prof_t_); prof_t_ = __builtin_readcyclecounter(); } } while (0)
-#define VR_PROF_BEGIN unsigned long long prof_t_ = __builtin_readcyclecounter()
-#define VR_PROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kProfBlocks) atomicAdd(&g_raster_prof[blockIdx.x * 8 + (i)], (unsigned long long)(v)); } while (0)
-extern "C" VR_API int vr_debug_raster_prof(unsigned long long out[8], int reset)
-{
-    static unsigned long long host[kProfBlocks * 8];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_raster_prof), sizeof(host)) != hipSuccess) return -1;
-    for (int i = 0; i < 8; i++) out[i] = 0;
-    for (int b = 0; b < kProfBlocks; b++) for (int i = 0; i < 8; i++) out[i] += host[b * 8 + i];
-    if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_prof), host, sizeof(host)) != hipSuccess) return -1; }
-    return 0;
-}
-#else
-#define VR_PROF_MARK(i) do { } while (0)
-#define VR_PROF_BEGIN do { } while (0)
-#define VR_PROF_ADD(i, v) do { } while (0)
-#endif
-
 // Workgroup size of the tile pass.  The visibility buffer (32 KB for a 64-pixel tile) admits four workgroups per CU;
 // how many waves that is per SIMD follows from the workgroup's size (256 threads: 4, 320: 5, 384: 6) if the kernel's
 // registers allow as many (<= 128 / 96 / 80).
@@ -996,6 +1112,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     __shared__ float thr[kThrTabSize];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
 #endif
+    __shared__ uint4 s_lv[kMaxLevels];                 // fast variant: DevTex::fast_lv (the same for both textures)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef VR_LDS_PAD      // experiments only: extra LDS per workgroup = fewer workgroups per CU (occupancy sensitivity of the tile pass)
     __shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
@@ -1005,8 +1122,9 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
+    if (MODE == RM_FAST && tid < kMaxLevels) s_lv[tid] = hm.fast_lv[tid];
 #ifndef VR_EXP_GLOBAL_TABLES
-    if (tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
+    if (MODE != RM_FAST && tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
     for (int i = tid; i < (kEncTabSize + 3) / 4; i += kRT) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
     if (tid < 256) thr[tid] = thr_g[tid];
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
@@ -1190,8 +1308,11 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     // ---- resolve: shade each pixel's winner once ------------------
     constexpr bool FAST = MODE == RM_FAST, DEPTH = MODE == RM_DEPTH, SAME = FAST;
     const bool depth_only = DEPTH || (!FAST && a.depth_only != 0);
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = FAST ? __builtin_amdgcn_make_buffer_rsrc((void*)hm.fast, (short)0, (int)hm.fast_bytes, 0x00020000)
+                                           : __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = FAST ? __builtin_amdgcn_make_buffer_rsrc((void*)al.fast, (short)0, (int)al.fast_bytes, 0x00020000)
+                                           : __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
+    const float w0f = (float)hm.w0, h0f = (float)hm.h0, max_level = (float)(hm.levels - 1);
     // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K;
     // the host launches the fast variant only then)
     const uint64_t gb_span = (uint64_t)(reinterpret_cast<const char*>(g_emi + (size_t)a.w * a.h) - reinterpret_cast<const char*>(g_depth));
@@ -1230,6 +1351,13 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         // the column's four visibility words ahead of the per-pixel control flow
         const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
         uint32_t pix = (uint32_t)__umul24(gy0, a.w) + (uint32_t)gx;          // < 2^28: both factors below 2^14
+#ifdef VR_EXP_TILED_STORES   // timing experiment only (scrambled image): every tile's pixels contiguous in each plane
+        uint32_t pix4 = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
+        const uint32_t w4 = (uint32_t)TILE << 2;
+#else
+        uint32_t pix4 = pix << 2;                                            // byte offset in a 4-byte plane (a row further: + 4 w)
+        const uint32_t w4 = (uint32_t)a.w << 2;
+#endif
         // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD: pixel k + 1's record is requested before pixel
         // k is shaded, so its round trip (entry -> record, a gather: every lane its own triangle) runs under pixel k's texel
         // fetches instead of in front of pixel k + 1's.  A pixel's chain of dependent memory accesses - visibility word,
@@ -1242,7 +1370,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         uint4 n5 = make_uint4(0, 0, 0, 0), n6 = n5, n7 = n5;                 // the NEXT pixel's record
         if (COVERED(0)) FETCH_REC(0, n5, n6, n7);
 #pragma unroll
-        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w) {
+        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4 += w4) {
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
             const uint4 g5 = n5, g6 = n6, g7 = n7;                            // this pixel's record (requested one pixel ago)
@@ -1252,6 +1380,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
             if (!cov && !a.assume_cleared) continue;               // keep what the target holds
             const uint32_t dep = (uint32_t)(key >> 32);
             uint32_t dif = 0, nn0 = 0, nn1 = 0;
+            VR_PROF_MARK(8);
             if (cov && !depth_only) {
                 const float q0 = __uint_as_float(g5.x), qx = __uint_as_float(g5.y), qy = __uint_as_float(g5.z);
                 const float nx0 = __uint_as_float(g6.x), nxx = __uint_as_float(g6.y), nxy = __uint_as_float(g6.z);
@@ -1264,24 +1393,32 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                     const float q = plane_at(q0, qx, qy, fdx, fdy);
                     // 1.0f / q: q = the interpolated 1/w of a point in front of the near plane, far inside the short sequence's
                     // range; anything else (a wire pixel far off its triangle's plane) is redone with the general division
+                    // (the fast variant has no wire pixels: inside its triangle a pixel's 1/w lies between its vertices')
                     const float aq = fabsf(q);
                     float r = vr_rcp_exact(q);
-                    if (__builtin_expect(__any(!(aq > 0x1p-60f && aq < 0x1p60f)), 0)) r = 1.0f / q;     // (wave-uniform, practically never taken)
+                    if (!FAST && __builtin_expect(__any(!(aq > 0x1p-60f && aq < 0x1p60f)), 0)) r = 1.0f / q;     // (wave-uniform, practically never taken)
                     p.wx = plane_at(nx0, nxx, nxy, fdx, fdy) * r;
                     p.wz = plane_at(nz0, nzx, nzy, fdx, fdy) * r;
                     p.dwxdx = __builtin_fmaf(-p.wx, qx, nxx) * r; p.dwzdx = __builtin_fmaf(-p.wz, qx, nzx) * r;
                     p.dwxdy = __builtin_fmaf(-p.wx, qy, nxy) * r; p.dwzdy = __builtin_fmaf(-p.wz, qy, nzy) * r;
                 }
-                pixel_shader<SAME, FAST>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
+                VR_PROF_MARK(9);
+                if (FAST) pixel_shader_fast(a, w0f, h0f, max_level, rq, rc, thr, enc, s_lv, p, dif, nn0, nn1 VR_PROF_ARG);
+                else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
+#ifdef VR_EXP_NOSTORE     // timing experiment only: nothing leaves (a dependent dummy keeps the shading alive)
+            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
+            continue;
+#endif
             if (gb_small) {
-                __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix << 2, 0, aux);
+                __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
                 if (!depth_only) {
-                    __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix << 2, o_diff, aux);
-                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix << 2, o_spec, aux);
+                    const uint32_t pix8 = pix4 + pix4;
+                    __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix4, o_diff, aux);
+                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
-                    __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix << 3, o_nrm, aux);
-                    __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix << 3, o_emi, aux);
+                    __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
+                    __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
                 }
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
@@ -1293,13 +1430,13 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                     ST2(g_emi + p64, 0u, 0u);
                 }
             }
+            VR_PROF_MARK(15);
         }
     }
 #undef ST1
 #undef ST2
 #undef COVERED
 #undef FETCH_REC
-    VR_PROF_MARK(6);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -3,6 +3,8 @@
 #include "vr_internal.h"
 #include "vr_tex_dev.h"
 
+#include <string.h>
+
 // 2x2 box downsample of an R8_UNORM level: round(avg * 255) == (sum + 2) >> 2.
 __global__ void k_mip_r8(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh)
 {
@@ -61,6 +63,25 @@ __global__ void k_build_quads_f32(const uint8_t* __restrict__ src, int w, int h,
     dst[(size_t)iy * (w + 2) + ix] = make_float4(t00, t10 - t00, t01, t11 - t01);
 }
 
+// Tables of the tile pass's fast variant (DevTex::fast): (w+3) x (h+3) clamp-addressed entries per level.
+__global__ void k_build_fast_r8(const uint8_t* __restrict__ src, int w, int h, float4* __restrict__ dst)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= w + 3 || iy >= h + 3) return;
+    const int x0 = min(max(ix - 1, 0), w - 1), x1 = min(max(ix, 0), w - 1);
+    const int y0 = min(max(iy - 1, 0), h - 1), y1 = min(max(iy, 0), h - 1);
+    const float t00 = (float)src[y0 * w + x0] / 255.0f, t10 = (float)src[y0 * w + x1] / 255.0f;
+    const float t01 = (float)src[y1 * w + x0] / 255.0f, t11 = (float)src[y1 * w + x1] / 255.0f;
+    dst[(size_t)iy * (w + 3) + ix] = make_float4(t00, t10 - t00, t01, t11 - t01);
+}
+__global__ void k_build_fast_srgba8(const uint32_t* __restrict__ src, int w, int h, const float* __restrict__ lut, float4* __restrict__ dst)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= w + 3 || iy >= h + 3) return;
+    const uint32_t p = src[(size_t)min(max(iy - 1, 0), h - 1) * w + min(max(ix - 1, 0), w - 1)];
+    dst[(size_t)iy * (w + 3) + ix] = make_float4(lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u], 0.0f);
+}
+
 __global__ void k_decode_rgbf(const uint32_t* __restrict__ src, size_t n, const float* __restrict__ lut, float* __restrict__ dst)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -103,7 +124,29 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
     }
     size_t rgbf_off = 0;
     if (tb == 4) { total = (total + 255) / 256 * 256; rgbf_off = total; total += table_off / 4 * 16; }   // decoded copy of the whole chain
-    VR_REQUIRE(total < ((size_t)1 << 31), "texture too large");        // texels are addressed with 32-bit byte offsets
+    // tables of the tile pass's fast variant: (w+3) x (h+3) entries of 16 B per level, levels 256-B aligned
+    uint32_t fast_lv[kMaxLevels][4];
+    size_t fast_entry[kMaxLevels];
+    memset(fast_lv, 0, sizeof(fast_lv));
+    total = (total + 255) / 256 * 256;
+    const size_t fastlv_off = total; total += sizeof(fast_lv);
+    total = (total + 255) / 256 * 256;
+    const size_t fast_off = total;
+    size_t fast_bytes = 0;
+    for (int l = 0; l < levels; l++) {
+        const int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
+        fast_entry[l] = fast_bytes / 16;
+        const uint32_t row = (uint32_t)(lw + 3) * 16u;
+        const float wf = (float)lw, hf = (float)lh;
+        fast_lv[l][0] = (uint32_t)fast_bytes + row + 16u; fast_lv[l][1] = row;
+        memcpy(&fast_lv[l][2], &wf, 4); memcpy(&fast_lv[l][3], &hf, 4);
+        fast_bytes += ((size_t)(lw + 3) * (lh + 3) * 16 + 255) / 256 * 256;
+    }
+    total += fast_bytes;
+    // every table is read through its own buffer resource with 32-bit byte offsets: each must stay below 2 GB
+    VR_REQUIRE(quad_dwords * sizeof(float4) < ((size_t)1 << 31) && table_off * 4 < ((size_t)1 << 31) && fast_bytes < ((size_t)1 << 31),
+               "texture too large");
+
     uint8_t* mem = nullptr;
     VR_HIP(hipMalloc(&mem, total));
     if (out_bytes) *out_bytes += total;
@@ -124,6 +167,15 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
         sw = dw; sh = dh;
     }
     out->quad = nullptr; out->qoff = nullptr; out->quadf = nullptr; out->rgbf = nullptr;
+    VR_TEX_TRY(hipMemcpyAsync(mem + fastlv_off, fast_lv, sizeof(fast_lv), hipMemcpyHostToDevice, s));
+    for (int l = 0; l < levels; l++) {
+        const int lw = (w >> l) > 1 ? (w >> l) : 1, lh = (h >> l) > 1 ? (h >> l) : 1;
+        dim3 blk(32, 8), grd((lw + 3 + 31) / 32, (lh + 3 + 7) / 8);
+        float4* dst = (float4*)(mem + fast_off) + fast_entry[l];
+        if (tb == 1) hipLaunchKernelGGL(k_build_fast_r8, grd, blk, 0, s, mem + off[l], lw, lh, dst);
+        else hipLaunchKernelGGL(k_build_fast_srgba8, grd, blk, 0, s, (const uint32_t*)(mem + off[l]), lw, lh, ctx->d_srgb_lut, dst);
+    }
+    out->fast = (const float4*)(mem + fast_off); out->fast_lv = (const uint4*)(mem + fastlv_off); out->fast_bytes = (uint32_t)fast_bytes; out->pad2 = 0;
     if (tb == 4) {       // (padding texels between levels are decoded too; nothing reads them)
         hipLaunchKernelGGL(k_decode_rgbf, dim3(4096), dim3(256), 0, s, (const uint32_t*)mem, table_off / 4, ctx->d_srgb_lut, (float*)(mem + rgbf_off));
         out->rgbf = (const float*)(mem + rgbf_off);

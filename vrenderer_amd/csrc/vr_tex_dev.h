@@ -40,19 +40,21 @@ __device__ __forceinline__ LodSplit vr_lod_split(int levels, float lod)
 
 // Implicit LOD from screen-space uv differences (isotropic, D3D11 7.18.11) with the
 // pinned cubic log2 (max error 1.1e-3 LOD) so every implementation agrees exactly.
-__device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
+__device__ __forceinline__ float vr_lod_from_derivs_f(float dudx, float dvdx, float dudy, float dvdy, float wf, float hf)
 {
-    float ax = dudx * (float)w, ay = dvdx * (float)h, bx = dudy * (float)w, by = dvdy * (float)h;
+    float ax = dudx * wf, ay = dvdx * hf, bx = dudy * wf, by = dvdy * hf;
     float r2x = __builtin_fmaf(ax, ax, ay * ay), r2y = __builtin_fmaf(bx, bx, by * by);      // fused sums of squares (oracle: lod_from_derivs)
-    float r2 = r2x > r2y ? r2x : r2y;
-    // (selects, not branches: the dozen instructions below cost less than two divergent branches around them)
+    float r2 = __builtin_fmaxf(r2x, r2y);
+    // 0.5 * log2(r2) from the bits, unconditionally (no compare / select): the caller clamps to [0, last level]
     uint32_t bits = __float_as_uint(r2);
     int e = (int)((bits >> 23) & 255u) - 127;
     float tt = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u) - 1.0f;
     float p = tt * __builtin_fmaf(tt, __builtin_fmaf(tt, 0.1563861f, -0.57725066f), 1.4208646f);
-    float lod = 0.5f * ((float)e + p);
-    lod = e >= 128 ? 64.0f : lod;                 // inf / NaN -> coarsest
-    return r2 > 1.0f ? lod : 0.0f;                // magnified (and NaN): level 0
+    return 0.5f * ((float)e + p);
+}
+__device__ __forceinline__ float vr_lod_from_derivs(float dudx, float dvdx, float dudy, float dvdy, int w, int h)
+{
+    return vr_lod_from_derivs_f(dudx, dvdx, dudy, dvdy, (float)w, (float)h);
 }
 
 // linear -> sRGB8: number of thresholds <= x (thr[0] = 0): round-to-nearest OETF.
