@@ -445,15 +445,22 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    ctx.timing_enable(True)          # HIP events around every kernel, on the stream they are launched on
+    # HIP events around every kernel, on the stream they are launched on.  A rank of an N-way split has a frame period
+    # near 0.1 ms: there two hipEventRecord calls around each of a frame's dozen small kernels make the LOOP host-bound
+    # (measured: host 164 us per frame with them, 60 without; tools/exp_host_cost.py), so the timed region times only the
+    # launches whose events the dispatch stamps (tile pass, lighting: level 2) and the small kernels are timed in a
+    # separate pass behind it.
+    timing_level = 2 if (use_dist or emu) else 1
+    ctx.timing_enable(timing_level)
     side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx_comm)) if c is not ctx]
     for c in side_ctxs:
-        c.timing_enable(True)
+        c.timing_enable(timing_level)
     if use_dist:
         xch_timed[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_issue = time.perf_counter() - t0       # host time to queue the timed frames (the device runs behind it)
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -463,6 +470,25 @@ def main():
     for c in side_ctxs:
         timings.update(c.timing_collect())
         c.timing_enable(False)
+    kernels_note = None
+    if timing_level == 2:
+        # the small kernels (geometry chain, tone-map stage, de-tile), timed with events around every launch over a few
+        # more frames OUTSIDE the timed region
+        extra = min(args.steps, 20)
+        for c in [ctx] + side_ctxs:
+            c.timing_enable(1)
+        for i in range(extra):
+            step(args.warmup + args.steps + i)
+        sync()
+        diag = ctx.timing_collect()
+        ctx.timing_enable(False)
+        for c in side_ctxs:
+            diag.update(c.timing_collect())
+            c.timing_enable(False)
+        for k, v in diag.items():
+            timings.setdefault(k, v)
+        kernels_note = (f"k_raster and the lighting kernel from the {args.steps} timed frames (dispatch-stamped events); every other kernel from "
+                        f"{extra} further frames timed with events around every launch, outside the timed region")
     n_nodes = tp.num_chunks()
     if tiled:
         deferred.Status()            # raises if a tile kept more than VR_TILE_LIGHT_CAP lights (the result would be truncated)
@@ -617,7 +643,11 @@ def main():
             "dominant_kernel_by_time": dominant,
             "kernels": kern,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
+            # how long the host needed to queue a frame: if this approaches ms_per_step the loop is host-bound, not device-bound
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
+        if kernels_note:
+            out["kernels_note"] = kernels_note
         if emu:
             out["emulation"] = {"rank": args.emulate_rank, "world": args.emulate_world, "owned_pixels": owned_px,
                                 "what": "one GPU computes this rank's share of the N-way screen-tile split per frame (geometry replicated, "

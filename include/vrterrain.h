@@ -162,7 +162,9 @@ VR_API const char* vr_version(void);
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
        VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS,
        VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_RASTER_DEPTH, VR_K_LIGHT_CULL, VR_K_COUNT };
-VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples */
+VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples; 1 = every kernel (two event records per
+                                                                * launch), 2 = only the tile pass and the lighting passes, whose
+                                                                * events the dispatch stamps at no host cost */
 /* Synchronises the stream; per kernel id: summed milliseconds and launch count since
  * the last enable/collect; resets the samples. */
 VR_API int  vr_timing_collect(vr_context* ctx, float ms_sum[VR_K_COUNT], int32_t launches[VR_K_COUNT]);

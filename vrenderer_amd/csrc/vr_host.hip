@@ -135,7 +135,10 @@ static hipEvent_t ring_event(vr_context* c)
 }
 VrKernelScope::VrKernelScope(vr_context* ctx, int id_, hipStream_t stream, bool attach_) : c(ctx), st(stream), attach(attach_), id(id_)
 {
-    if (c->timing) {
+    // level 2: only the launches whose events are stamped by the dispatch itself (the tile pass, the lighting passes): timing
+    // them costs the host nothing, while two hipEventRecord calls around each of a frame's dozen small kernels make a loop
+    // with a ~110 us frame period host-bound
+    if (c->timing == 1 || (c->timing == 2 && attach)) {
         e0 = take_event(c); e1 = take_event(c);
         if (!e0 || !e1) {
             if (e0) c->ev_pool.push_back(e0);
@@ -181,7 +184,7 @@ extern "C" VR_API int vr_timing_enable(vr_context* c, int enable)
     // pairs recorded on a terrain's geometry stream may still be pending: wait for each before its events are recycled
     for (hipEvent_t e : c->ev_end) (void)hipEventSynchronize(e);
     timing_reset(c);
-    c->timing = enable != 0;
+    c->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return VR_OK;
 }
 extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT], int32_t launches[VR_K_COUNT])

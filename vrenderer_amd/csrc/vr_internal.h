@@ -139,7 +139,7 @@ struct vr_context {
     uint32_t* d_light_lists = nullptr; size_t light_list_words = 0;    // per 32x32 light tile: count + light indices (k_light_cull)
     uint32_t* d_flags = nullptr;
     // per-kernel timing (vr_timing_*): event pairs recorded on `stream`
-    bool timing = false;
+    int timing = 0;                      // 0 off, 1 every kernel (two event records each), 2 only the launches whose events the dispatch stamps
     std::vector<hipEvent_t> ev_pool;     // reusable events
     std::vector<hipEvent_t> ev_begin, ev_end;
     std::vector<int> ev_id;
@@ -271,6 +271,14 @@ int vr_terrain_pick_set(vr_terrain* t);
 int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out);
 // any cached table set of (w, h, world): the slot table does not depend on the rank
 int vr_partition_slot_tables(vr_context* ctx, int w, int h, int world, const PartTables** out);
+
+// The geometry kernels (select, vertex, setup, clip, scan, fill) are short and latency-bound and run on CUs full of
+// tile-pass waves: they raise their waves' issue priority so that their few instructions are not queued behind the tile
+// pass's many (the sequencer arbitrates by priority, then age).
+#ifndef VR_GEOMETRY_PRIO
+#define VR_GEOMETRY_PRIO 3
+#endif
+#define VR_GEOMETRY_PRIORITY() __builtin_amdgcn_s_setprio(VR_GEOMETRY_PRIO)
 
 // ---- device helpers shared by kernels ---------------------------------------------------
 __device__ __forceinline__ float vr_max(float a, float b) { return a > b ? a : b; }

@@ -94,6 +94,7 @@ __device__ __forceinline__ void snap_vertex(DevVert& v, float vp_x, float vp_y, 
 __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const vr_instance* __restrict__ inst,
                                                  uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
 {
+    VR_GEOMETRY_PRIORITY();
     // first kernel of every frame: reset the frame's work counters (k_setup is the first to use them)
     if (blockIdx.x == 0 && threadIdx.x < 6) counters[2 + threadIdx.x] = 0u;
     __shared__ float r8[256];
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __re
                                                 uint64_t* __restrict__ rect, uint32_t* __restrict__ hard_list,
                                                 uint32_t* __restrict__ tile_count, uint4* __restrict__ recs)
 {
+    VR_GEOMETRY_PRIORITY();
     const uint32_t total = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < total; tri += gridDim.x * blockDim.x) {
         uint32_t i0, i1, i2;
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
                                               uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count,
                                               uint4* __restrict__ hard_recs)
 {
+    VR_GEOMETRY_PRIORITY();
     const uint32_t n_hard = min(counters[C_HARDLIST], a.hard_cap);
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_hard; h += gridDim.x * blockDim.x) {
         const uint32_t tri = hard_list[h];
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict
                                                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity,
                                                 const int32_t* __restrict__ cand, int n_cand, int32_t* __restrict__ order)
 {
+    VR_GEOMETRY_PRIORITY();
     __shared__ uint32_t s_wsum[16];                       // per wave: sum of its threads' counts -> exclusive base
     __shared__ uint32_t s_cls[kScanClasses * 16];         // per (class, wave): tiles of that class -> first slot in `order`
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -601,6 +605,7 @@ __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __re
                                                const HardTriRec* __restrict__ hard_tris, uint32_t* __restrict__ tile_cursor,
                                                uint32_t* __restrict__ entries)
 {
+    VR_GEOMETRY_PRIORITY();
     const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     const uint32_t n_hard = min(counters[C_HARDTRIS], a.hard_cap * 4u);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reg + n_hard; i += gridDim.x * blockDim.x) {

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
                                                         vr_instance* __restrict__ inst, uint32_t* __restrict__ counters,
                                                         const float2* __restrict__ heights, uint32_t* __restrict__ scratch)
 {
+    VR_GEOMETRY_PRIORITY();
     __shared__ uint32_t frontier[2][kFrontLds];
     __shared__ uint32_t chunk[kRankChunk];
     __shared__ uint32_t n_front[2], n_sel, overflow;

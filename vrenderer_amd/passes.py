@@ -45,6 +45,7 @@ class Context:
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_DISPATCH_EVENTS, int(enable)), "vr_context_set_option")
 
     def timing_enable(self, enable=True):
+        """0 / False: off; 1 / True: events around every kernel; 2: only the tile pass and the lighting passes (no host cost)."""
         check(self.lib.vr_timing_enable(self.handle, int(enable)), "vr_timing_enable")
 
     def timing_collect(self):
