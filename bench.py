@@ -445,12 +445,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    # HIP events around every kernel, on the stream they are launched on.  A rank of an N-way split has a frame period
-    # near 0.1 ms: there two hipEventRecord calls around each of a frame's dozen small kernels make the LOOP host-bound
-    # (measured: host 164 us per frame with them, 60 without; tools/exp_host_cost.py), so the timed region times only the
-    # launches whose events the dispatch stamps (tile pass, lighting: level 2) and the small kernels are timed in a
-    # separate pass behind it.
-    timing_level = 2 if (use_dist or emu) else 1
+    # HIP events on the stream each kernel is launched on.  The timed region times the launches whose events the dispatch
+    # itself stamps - the tile pass and the lighting pass (level 2: no host call, no extra packet) - and the small kernels
+    # (geometry chain, tone-map stage, de-tile) are timed with event records around every launch in a separate pass behind
+    # it: two hipEventRecord calls around each of a frame's dozen small kernels cost the 8K frame 30 us (557 -> 590 us) and
+    # make a rank's loop of an 8-way split, whose frame period is near 0.1 ms, host-bound (host 164 us per frame with
+    # them, 60 without; tools/exp_host_cost.py).
+    timing_level = 2
     ctx.timing_enable(timing_level)
     side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx_comm)) if c is not ctx]
     for c in side_ctxs:

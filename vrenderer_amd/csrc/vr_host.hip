@@ -111,11 +111,19 @@ extern "C" VR_API int vr_context_synchronize(vr_context* c)
 }
 
 // ---- per-kernel timing ---------------------------------------------------------------
+// Events that order device work against device work (and time kernels) need no system-scope fence: nothing here hands data
+// to the host through them - downloads go through stream synchronisation.  Without the flag every stamped event ends its
+// kernel with a release to system scope (a write-back of the caches) in front of the next dispatch.
+static unsigned vr_event_flags()
+{
+    static const unsigned flags = getenv("VR_EVENT_SYSTEM_FENCE") ? hipEventDefault : hipEventDisableSystemFence;
+    return flags;
+}
 static hipEvent_t take_event(vr_context* c)
 {
     hipEvent_t e = nullptr;
     if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e, vr_event_flags()) != hipSuccess) return nullptr;
     return e;
 }
 VrKernelScope::VrKernelScope(vr_context* ctx, int id) : VrKernelScope(ctx, id, ctx->stream) {}
@@ -125,7 +133,7 @@ static hipEvent_t ring_event(vr_context* c)
     constexpr size_t kRing = 64;          // far more than the launches a later wait can still refer to
     if (c->ev_ring.size() < kRing) {
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e, vr_event_flags()) != hipSuccess) return nullptr;
         c->ev_ring.push_back(e);
         return e;
     }
@@ -172,6 +180,8 @@ VrKernelScope::~VrKernelScope()
 
 static void timing_reset(vr_context* c)
 {
+    c->ev_epoch++;                     // every handle to a pooled event taken before this point is stale now
+    c->last_stop = nullptr;
     for (hipEvent_t e : c->ev_begin) c->ev_pool.push_back(e);
     for (hipEvent_t e : c->ev_end) c->ev_pool.push_back(e);
     c->ev_begin.clear(); c->ev_end.clear(); c->ev_id.clear();

@@ -133,6 +133,10 @@ struct vr_context {
     bool dispatch_events = true;
     std::vector<hipEvent_t> ev_ring; size_t ev_ring_pos = 0;
     hipEvent_t last_stop = nullptr;     // stop event of the most recent dispatch-stamped launch on `stream`
+    // Handles to pooled timing events are only good until the pool is recycled (vr_timing_enable / vr_timing_collect, both
+    // of which synchronise the stream first): holders remember the epoch and treat a handle of an older epoch as 'already
+    // complete' instead of waiting on an event that may since have been re-recorded for an unrelated kernel.
+    uint64_t ev_epoch = 1;
     // light list of vr_deferred_light_tiled
     DevLight* d_lights = nullptr; size_t light_capacity = 0; std::vector<DevLight> h_lights, h_lights_on_device;   // (the list d_lights holds)
     uint32_t* d_macro_scratch = nullptr; size_t macro_scratch_words = 0;   // per macro tile: lights touching its box (k_light_cull's first stage)
@@ -210,6 +214,7 @@ struct GeoSet {
     int scratch_tiles = 0;
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
     hipEvent_t raster_done = nullptr;    // what the geometry stream waits on before reusing this set: ev_raster_done, or the tile pass's own stop event
+    uint64_t raster_done_epoch = 0;      // 0: raster_done is this set's own ev_raster_done (always valid); else the context's ev_epoch when the handle was taken
     bool raster_recorded = false, have_selection = false;
     // Successive chains on one set may run on different geometry streams (they take turns) and a chain is not always
     // consumed by a tile pass (an evicted prepared set, vr_terrain_select alone): every writer of the set first waits for
@@ -217,6 +222,7 @@ struct GeoSet {
     bool geo_recorded = false;           // ev_geo_done has been recorded at least once
     hipEvent_t ev_sel_read = nullptr;    // recorded behind a lock_view copy OUT of this set (on the copying set's stream)
     bool sel_read_pending = false;
+    bool main_waited = false;            // the context's stream already waits for this set's chain (queued by vr_terrain_prepare)
     // The geometry stream this set's last chain ran on (the terrain's two streams take turns, so that two prepared
     // frames have their latency-bound chains in flight at once).
     hipStream_t stream = nullptr;
@@ -258,6 +264,7 @@ struct vr_terrain {
     hipEvent_t ev_main_dep = nullptr, ev_raster_begin = nullptr;   // ev_raster_begin: the context's stream reached the last tile pass
     bool raster_begin_recorded = false;
     hipEvent_t start_hint = nullptr;        // vr_terrain_prepare starts its geometry behind this: ev_raster_begin, or the previous lighting pass's stop event
+    uint64_t start_hint_epoch = 0;          // as GeoSet::raster_done_epoch
 };
 
 struct vr_tonemap;

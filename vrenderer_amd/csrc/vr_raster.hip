@@ -1489,6 +1489,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
     // is ordered by the events below: its previous chain (consumed by a tile pass or not), the tile pass that read it, and
     // a lock_view copy of its selection into another set.
     g.stream = t->geo_streams[t->geo_turn++ & 1u];
+    g.main_waited = false;
     hipStream_t s = ctx->stream, gs = g.stream;
     if (!ctx->async_geometry) {          // single-stream mode: order the geometry behind everything queued so far
         VR_HIP(hipEventRecord(t->ev_main_dep, s));
@@ -1497,7 +1498,8 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
     // after the tile pass that last read this set, and after anything the context's stream did to the terrain
     if (g.geo_recorded) VR_HIP(hipStreamWaitEvent(gs, g.ev_geo_done, 0));
     if (g.sel_read_pending) { VR_HIP(hipStreamWaitEvent(gs, g.ev_sel_read, 0)); g.sel_read_pending = false; }
-    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(gs, g.raster_done, 0));
+    // (a stop event of an older timing epoch: the stream was synchronised when the pool was recycled - that tile pass is done)
+    if (g.raster_recorded && (g.raster_done_epoch == 0 || g.raster_done_epoch == ctx->ev_epoch)) VR_HIP(hipStreamWaitEvent(gs, g.raster_done, 0));
     if (g.main_dep_pending) { VR_HIP(hipStreamWaitEvent(gs, t->ev_main_dep, 0)); g.main_dep_pending = false; }
     int rc;
     if (selection_from == nullptr) {                                   // TerrainPass.cpp:173-190
@@ -1591,8 +1593,14 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     // with the previous frame's lighting pass (bandwidth-bound) instead of with a tile pass (which leaves
     // half of every CU's wave slots free).  (Measured again in round 2, 8K: geometry under the tile pass 483 + 211 us,
     // frame 0.715 ms; geometry under the lighting pass 462 + 239 us, frame 0.723 ms.)
-    if (t->raster_begin_recorded) VR_HIP(hipStreamWaitEvent(t->geo_streams[t->geo_turn & 1u], t->start_hint, 0));   // (the stream launch_geometry takes next)
+    if (t->raster_begin_recorded && (t->start_hint_epoch == 0 || t->start_hint_epoch == t->ctx->ev_epoch))
+        VR_HIP(hipStreamWaitEvent(t->geo_streams[t->geo_turn & 1u], t->start_hint, 0));   // (the stream launch_geometry takes next)
     if ((rc = launch_geometry(t, g, nullptr, view, rp, a, pt))) return rc;
+    // The context's stream waits for this chain NOW - in a frame loop that is in front of the current frame's lighting pass,
+    // which the chain (started under the current tile pass, ~150 us) has long finished by - instead of in front of the tile
+    // pass that will consume it: the lighting pass -> tile pass boundary then holds no cross-stream wait.
+    VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0));
+    g.main_waited = true;
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
     g.prep_serial = ++t->prep_counter;
     return VR_OK;
@@ -1627,14 +1635,15 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         if ((rc = launch_geometry(t, g, sel, view, rp, a, pt))) return rc;
     }
     t->cur = gi;
-    VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));                    // the tile pass consumes verts + bins
+    if (!(use_prepared && g.main_waited)) VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));     // the tile pass consumes verts + bins
+    g.main_waited = false;
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
     const int grid = pt ? pt->num_raster_tiles : a.rtx * a.rty;
     // vr_terrain_prepare's start hint: "the context's stream has reached this tile pass".  With dispatch-stamped events that
     // is the stop event of whatever ran last on the stream (the previous frame's lighting pass); else an explicit record.
-    if (ctx->dispatch_events && ctx->last_stop) { t->start_hint = ctx->last_stop; t->raster_begin_recorded = true; }
-    else { VR_HIP(hipEventRecord(t->ev_raster_begin, s)); t->start_hint = t->ev_raster_begin; t->raster_begin_recorded = true; }
+    if (ctx->dispatch_events && ctx->last_stop) { t->start_hint = ctx->last_stop; t->start_hint_epoch = ctx->ev_epoch; t->raster_begin_recorded = true; }
+    else { VR_HIP(hipEventRecord(t->ev_raster_begin, s)); t->start_hint = t->ev_raster_begin; t->start_hint_epoch = 0; t->raster_begin_recorded = true; }
     hipEvent_t pass_stop = nullptr;
     if (grid > 0) {
         // a depth-only tile pass (the shadow map's) is timed under its own id: it is an order of magnitude shorter than the
@@ -1657,8 +1666,8 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
     }
-    if (pass_stop) g.raster_done = pass_stop;
-    else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; }
+    if (pass_stop) { g.raster_done = pass_stop; g.raster_done_epoch = ctx->ev_epoch; }
+    else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; g.raster_done_epoch = 0; }
     g.raster_recorded = true;
     VR_HIP(hipGetLastError());
     return VR_OK;

@@ -605,7 +605,7 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
     // the set's previous chain may have run on the other geometry stream and may never have been rastered
     if (g.geo_recorded) VR_HIP(hipStreamWaitEvent(g.stream, g.ev_geo_done, 0));
     if (g.sel_read_pending) { VR_HIP(hipStreamWaitEvent(g.stream, g.ev_sel_read, 0)); g.sel_read_pending = false; }
-    if (g.raster_recorded) VR_HIP(hipStreamWaitEvent(g.stream, g.raster_done, 0));
+    if (g.raster_recorded && (g.raster_done_epoch == 0 || g.raster_done_epoch == t->ctx->ev_epoch)) VR_HIP(hipStreamWaitEvent(g.stream, g.raster_done, 0));
     g.prepared = false;
     int rc = vr_select_launch(t, g, view, max_height, g.stream);
     if (rc) return rc;
