@@ -867,9 +867,23 @@ __device__ __forceinline__ FastTaps issue_level_fast(__amdgpu_buffer_rsrc_t rq, 
     FAST_AXIS(t.fy0, y0, v0, hf, 1.0f); FAST_AXIS(t.fya, ya, va, hf, 1.0f); FAST_AXIS(t.fyb, yb, vb, hf, 1.0f);
     const uint32_t row0 = L.x + (uint32_t)__mul24(y0, (int)L.y), rowa = L.x + (uint32_t)__mul24(ya, (int)L.y), rowb = L.x + (uint32_t)__mul24(yb, (int)L.y);
 #define LD(r_, o_) __builtin_amdgcn_raw_buffer_load_b128((r_), (o_), 0, 0)
+#ifdef VR_EXP_FAST_SAMEADDR   // timing experiments only (wrong image): every fetch at the table's first entries / fewer fetches per level
+    t.e0 = LD(rq, (row0 + (uint32_t)xa) & 0xf0u); t.e1 = LD(rq, (row0 + (uint32_t)xb) & 0xf0u); t.e2 = LD(rq, (rowa + (uint32_t)x0) & 0xf0u); t.e3 = LD(rq, (rowb + (uint32_t)x0) & 0xf0u);
+    const uint32_t a00 = (row0 + (uint32_t)x0) & 0xf0u, a01 = a00 + 256u;
+    t.p00 = LD(rc, a00); t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u);
+#elif defined(VR_EXP_FAST_ALB1)
+    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0);
+    const uint32_t a00 = row0 + (uint32_t)x0;
+    t.p00 = LD(rc, a00); t.p10 = t.p00; t.p01 = t.p00; t.p11 = t.p00;
+#elif defined(VR_EXP_FAST_HGT1)
+    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = t.e0; t.e2 = t.e0; t.e3 = t.e0; (void)rowa; (void)rowb; (void)xb;
+    const uint32_t a00 = row0 + (uint32_t)x0;
+    t.p00 = LD(rc, a00); t.p10 = t.p00; t.p01 = t.p00; t.p11 = t.p00;
+#else
     t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0);
     const uint32_t a00 = row0 + (uint32_t)x0, a01 = a00 + L.y;
     t.p00 = LD(rc, a00); t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u);
+#endif
 #undef LD
     return t;
 }
@@ -912,7 +926,11 @@ __device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f
     }
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
+#ifdef VR_EXP_FAST_NOLEVEL1  // timing experiment only (wrong image): no coarser level
+    if (a.w < 0) {
+#else
     if (__any(frac > 0.0f)) {
+#endif
         const int l16b = (int)(fminf(lf + 1.0f, max_level) * 16.0f);
         // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
         float xa = ua, xb = ub, ya = va, yb = vb, x0 = u, y0 = v;
@@ -1307,6 +1325,11 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         }
         VR_PROF_MARK(4);
     }
+#ifdef VR_EXP_LDSREC
+    __shared__ uint4 s_rec[64 * 3];
+    if (tid < 64 * 3 && n > 0 && off < a.bin_capacity)
+        s_rec[tid] = recs[rec_index(entries[off], hard_first, rec_hard_base) * kRecGroups + 5 + tid % 3];
+#endif
     __syncthreads();
     VR_PROF_MARK(5);
 
@@ -1357,10 +1380,10 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
         uint32_t pix = (uint32_t)__umul24(gy0, a.w) + (uint32_t)gx;          // < 2^28: both factors below 2^14
 #ifdef VR_EXP_TILED_STORES   // timing experiment only (scrambled image): every tile's pixels contiguous in each plane
-        uint32_t pix4 = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
+        uint32_t pix4_ = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
         const uint32_t w4 = (uint32_t)TILE << 2;
 #else
-        uint32_t pix4 = pix << 2;                                            // byte offset in a 4-byte plane (a row further: + 4 w)
+        uint32_t pix4_ = pix << 2;                                           // byte offset in a 4-byte plane (a row further: + 4 w)
         const uint32_t w4 = (uint32_t)a.w << 2;
 #endif
         // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD: pixel k + 1's record is requested before pixel
@@ -1370,12 +1393,16 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         // number of fetches: three albedo fetches fewer per level changed the pass by 1 % (profiles/r03_tile_pass_experiments.txt).
         // (A record is fetched even when the lane's triangle did not change: a hit in the L1, and no divergent branch.)
 #define COVERED(k_) ((uint32_t)keys[k_] != 0xffffffffu && (whole || gy0 + (k_) < a.h) && !depth_only)
+#ifdef VR_EXP_LDSREC      // timing experiment only (wrong image): every pixel's planes come from an LDS copy of the tile's first record
+#define FETCH_REC(k_, r5_, r6_, r7_) do { const uint4* rp_ = s_rec + ((uint32_t)keys[k_] & 63u) * 3u; r5_ = rp_[0]; r6_ = rp_[1]; r7_ = rp_[2]; } while (0)
+#else
 #define FETCH_REC(k_, r5_, r6_, r7_) do { const uint4* __restrict__ rp_ = recs + rec_index(key_of((uint32_t)keys[k_]), hard_first, rec_hard_base) * kRecGroups; \
                                           r5_ = rp_[5]; r6_ = rp_[6]; r7_ = rp_[7]; } while (0)
+#endif
         uint4 n5 = make_uint4(0, 0, 0, 0), n6 = n5, n7 = n5;                 // the NEXT pixel's record
         if (COVERED(0)) FETCH_REC(0, n5, n6, n7);
 #pragma unroll
-        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4 += w4) {
+        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4_ += w4) {
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
             const uint4 g5 = n5, g6 = n6, g7 = n7;                            // this pixel's record (requested one pixel ago)
@@ -1412,18 +1439,25 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                 else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
 #ifdef VR_EXP_NOSTORE     // timing experiment only: nothing leaves (a dependent dummy keeps the shading alive)
-            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
+            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4_, 0, aux);
             continue;
 #endif
             if (gb_small) {
+#ifdef VR_EXP_STOREWIN    // timing experiment only (wrong image): every store lands in a 256-KB window of its plane - same instructions, no HBM traffic
+                const uint32_t pix4 = pix4_ & 0x3fffcu;
+#else
+                const uint32_t pix4 = pix4_;
+#endif
                 __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
                 if (!depth_only) {
                     const uint32_t pix8 = pix4 + pix4;
                     __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix4, o_diff, aux);
-                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
                     __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
+#if !defined(VR_EXP_NOCONST) && !defined(VR_EXP_WIDECONST)   // timing experiments only (wrong image): the two constant planes are not written / written 16 bytes per lane
+                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
+#endif
                 }
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
@@ -1437,6 +1471,17 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
             }
             VR_PROF_MARK(15);
         }
+#ifdef VR_EXP_WIDECONST   // timing experiment only (uncovered pixels get the covered constant): the strip's constant planes as three 16-byte stores per lane
+        if (gb_small && !depth_only) {
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            const u4 sv = { spec_const, spec_const, spec_const, spec_const }, zv4 = { 0u, 0u, 0u, 0u };
+            const uint32_t sp = ((uint32_t)__umul24(gy0 + (lane >> 4), a.w) + (uint32_t)(ox + 4 * (lane & 15))) << 2;
+            __builtin_amdgcn_raw_buffer_store_b128(sv, rgb, sp, o_spec, aux);
+            const uint32_t e0 = ((uint32_t)__umul24(gy0 + (lane >> 5), a.w) + (uint32_t)(ox + 2 * (lane & 31))) << 3;
+            __builtin_amdgcn_raw_buffer_store_b128(zv4, rgb, e0, o_emi, aux);
+            __builtin_amdgcn_raw_buffer_store_b128(zv4, rgb, e0 + ((uint32_t)a.w << 4), o_emi, aux);
+        }
+#endif
     }
 #undef ST1
 #undef ST2
@@ -1596,11 +1641,18 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     if (t->raster_begin_recorded && (t->start_hint_epoch == 0 || t->start_hint_epoch == t->ctx->ev_epoch))
         VR_HIP(hipStreamWaitEvent(t->geo_streams[t->geo_turn & 1u], t->start_hint, 0));   // (the stream launch_geometry takes next)
     if ((rc = launch_geometry(t, g, nullptr, view, rp, a, pt))) return rc;
-    // The context's stream waits for this chain NOW - in a frame loop that is in front of the current frame's lighting pass,
-    // which the chain (started under the current tile pass, ~150 us) has long finished by - instead of in front of the tile
-    // pass that will consume it: the lighting pass -> tile pass boundary then holds no cross-stream wait.
-    VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0));
-    g.main_waited = true;
+    // Where the context's stream waits for this chain.  Never in front of the tile pass that consumes it (the lighting pass ->
+    // tile pass boundary then holds no cross-stream wait) and never earlier than it has to:
+    //   - the only prepared set (a loop that prepares one frame ahead): NOW - in a frame loop that is in front of the current
+    //     frame's lighting pass, a whole tile pass after the chain started;
+    //   - another frame is prepared already (two frames ahead: this chain is not the next tile pass's): behind the NEXT tile
+    //     pass (vr_terrain_render queues it), a whole frame later.  Below 8K a chain under load (~0.2 ms) outlasts the tile
+    //     pass it starts under (4K: 0.15 ms), and a wait in front of the current lighting pass stalled every frame by the
+    //     difference (4K: 0.28 -> 0.22 ms per frame without it).
+    bool other_prepared = false;
+    for (const GeoSet& p : t->sets) other_prepared |= (&p != &g) && p.prepared;
+    if (other_prepared) g.main_waited = false;
+    else { VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0)); g.main_waited = true; }
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
     g.prep_serial = ++t->prep_counter;
     return VR_OK;
@@ -1669,6 +1721,9 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     if (pass_stop) { g.raster_done = pass_stop; g.raster_done_epoch = ctx->ev_epoch; }
     else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; g.raster_done_epoch = 0; }
     g.raster_recorded = true;
+    // chains prepared further ahead whose wait vr_terrain_prepare left for later: behind this tile pass
+    for (GeoSet& p : t->sets)
+        if (&p != &g && p.prepared && !p.main_waited && p.geo_recorded) { VR_HIP(hipStreamWaitEvent(s, p.ev_geo_done, 0)); p.main_waited = true; }
     VR_HIP(hipGetLastError());
     return VR_OK;
 }
