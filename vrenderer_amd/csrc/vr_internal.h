@@ -198,7 +198,7 @@ constexpr int kGeoSets = 3;
 struct GeoSet {
     uint32_t* d_node_ids = nullptr;      // select outputs
     vr_instance* d_instances = nullptr;
-    uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..5] frame work counters
+    uint32_t* d_counters = nullptr;      // [0] selected count, [1] status flags, [2..7] frame work counters
     uint32_t* d_sel_scratch = nullptr;   // k_select: the frontiers' overflow beyond their LDS part and the selected keys (one workgroup's scratch)
     DevVert* d_verts = nullptr;          // max_instances*1089 regular + extra (clipper) region
     uint64_t* d_rect = nullptr;          // per triangle: tile rect or ~0 when culled

@@ -7,10 +7,13 @@
 //              served by L2/Infinity Cache; output 48 B/vertex (clip + snapped).
 //   k_setup  : one lane per triangle; cull (frustum, back-face, no-sample) and count
 //              the 64x64 raster tiles it touches (global atomics, ~1 per triangle).
-//              Triangles that cross the near plane / leave the guard band go to a
-//              small list for k_clip, which emits explicit sub-triangles.
-//   k_scan/k_fill : two-pass bin fill.  Order inside a bin is arbitrary — depth ties
-//              are resolved by a draw-order key, not by arrival order.
+//              Triangles that cross the near plane /
+//              leave the guard band go to a small list for the clipper, which emits explicit
+//              sub-triangles (k_clip).
+//   k_scan   : a slice of the entry array per tile (workgroup-local scans + one atomic each)
+//              and the tile pass's launch order.
+//   k_fill   : second pass of the bin fill.  Order inside a bin is
+//              arbitrary — depth ties are resolved by a draw-order key, not by arrival order.
 //   k_raster : one workgroup per raster tile.  A 64x64 x u64 visibility buffer
 //              (32 KiB LDS) holds (depth bits << 32 | ~draw order) per pixel; LessOrEqual
 //              in-order depth testing == 64-bit ds_min.  Small triangles are rasterised by
@@ -52,8 +55,9 @@ struct RasterArgs {
 };
 
 // counters[]: 0 selected nodes, 1 status flags, 2 hard sub-triangles, 3 extra verts,
-//             4 hard-list length, 5 total bin entries
-enum { C_COUNT = 0, C_FLAGS = 1, C_HARDTRIS = 2, C_XVERTS = 3, C_HARDLIST = 4, C_BINTOTAL = 5 };
+//             4 hard-list length, 5 total bin entries, 8..15 raster tiles per bin-length class (k_scan)
+// (2..15 are reset by k_vertex, the first kernel of a chain that uses them)
+enum { C_COUNT = 0, C_FLAGS = 1, C_HARDTRIS = 2, C_XVERTS = 3, C_HARDLIST = 4, C_BINTOTAL = 5, C_CLASS0 = 8 };
 
 
 // One bilinear tap through the quad (footprint) table, split into address and filter so that the
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
 {
     VR_GEOMETRY_PRIORITY();
     // first kernel of every frame: reset the frame's work counters (k_setup is the first to use them)
-    if (blockIdx.x == 0 && threadIdx.x < 6) counters[2 + threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 14) counters[2 + threadIdx.x] = 0u;
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels];
     r8[threadIdx.x] = (float)threadIdx.x / 255.0f;     // UNORM8 -> float, correctly rounded
@@ -354,6 +358,19 @@ __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32
         todo &= ~same;
     }
     if (live && !single) {
+        if (FILL && tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
+            // up to 2 x 2 tiles (most of what is left: a terrain cell is about a tile wide): the slots of all four are
+            // claimed before the first one is used - four atomics in flight instead of four round trips in a row
+            uint32_t pos[4]; bool use[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+                use[q] = tx <= tx1 && ty <= ty1 && tile_owned(a, tx, ty);
+                pos[q] = use[q] ? atomicAdd(&counters_or_cursor[ty * a.rtx + tx], 1u) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (use[q] && pos[q] < a.bin_capacity) entries[pos[q]] = entry;
+        } else
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++)
                 if (tile_owned(a, tx, ty)) {
@@ -364,48 +381,7 @@ __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32
 }
 
 // ---------------------------------------------------------------------------------------
-// k_setup: regular triangles
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
-                                                uint64_t* __restrict__ rect, uint32_t* __restrict__ hard_list,
-                                                uint32_t* __restrict__ tile_count, uint4* __restrict__ recs)
-{
-    VR_GEOMETRY_PRIORITY();
-    const uint32_t total = counters[C_COUNT] * (uint32_t)kTrisPerInst;
-    for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < total; tri += gridDim.x * blockDim.x) {
-        uint32_t i0, i1, i2;
-        regular_tri_indices(tri, i0, i1, i2);
-        const float4 c0 = *reinterpret_cast<const float4*>(&verts[i0].cx);
-        const float4 c1 = *reinterpret_cast<const float4*>(&verts[i1].cx);
-        const float4 c2 = *reinterpret_cast<const float4*>(&verts[i2].cx);
-        // trivial reject against the six clip planes
-        const bool out_l = (c0.x < -c0.w) && (c1.x < -c1.w) && (c2.x < -c2.w);
-        const bool out_r = (c0.x > c0.w) && (c1.x > c1.w) && (c2.x > c2.w);
-        const bool out_b = (c0.y < -c0.w) && (c1.y < -c1.w) && (c2.y < -c2.w);
-        const bool out_t = (c0.y > c0.w) && (c1.y > c1.w) && (c2.y > c2.w);
-        const bool out_n = (c0.z < 0.0f) && (c1.z < 0.0f) && (c2.z < 0.0f);
-        const bool out_f = (c0.z > c0.w) && (c1.z > c1.w) && (c2.z > c2.w);
-        uint64_t r = ~0ull;
-        if (!(out_l || out_r || out_b || out_t || out_n || out_f)) {
-            const bool need_near = (c0.z < 0.0f) || (c1.z < 0.0f) || (c2.z < 0.0f);
-            const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-            const bool need_guard = (c0.x < -g0) || (c0.x > g0) || (c0.y < -g0) || (c0.y > g0)
-                                 || (c1.x < -g1) || (c1.x > g1) || (c1.y < -g1) || (c1.y > g1)
-                                 || (c2.x < -g2) || (c2.x > g2) || (c2.y < -g2) || (c2.y > g2);
-            if (need_near || need_guard) {
-                const uint32_t slot = atomicAdd(&counters[C_HARDLIST], 1u);
-                if (slot < a.hard_cap) hard_list[slot] = tri; else atomicOr(&counters[C_FLAGS], 2u);
-            } else {
-                r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), recs + (size_t)tri * kRecGroups);
-            }
-        }
-        bin_rect<false>(a, r, 0u, tile_count, nullptr);
-        rect[tri] = r;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// k_clip: triangles crossing z = 0 or leaving the guard band (rare)
+// clipper: triangles crossing z = 0 or leaving the guard band (rare)
 // ---------------------------------------------------------------------------------------
 struct ClipVert { float c[4]; float wx, wz; };
 
@@ -446,14 +422,13 @@ __device__ int clip_poly(ClipVert* poly, int n, int plane)
     return m;
 }
 
-__global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
-                                              const uint32_t* __restrict__ hard_list, HardTriRec* __restrict__ hard_tris,
-                                              uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count,
-                                              uint4* __restrict__ hard_recs)
+// Entries first .. n_hard (step `step`) of the hard list.
+__device__ __forceinline__ void clip_hard_list(const RasterArgs& a, DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
+                                            const uint32_t* __restrict__ hard_list, HardTriRec* __restrict__ hard_tris,
+                                            uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count,
+                                            uint4* __restrict__ hard_recs, uint32_t first, uint32_t n_hard, uint32_t step)
 {
-    VR_GEOMETRY_PRIORITY();
-    const uint32_t n_hard = min(counters[C_HARDLIST], a.hard_cap);
-    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_hard; h += gridDim.x * blockDim.x) {
+    for (uint32_t h = first; h < n_hard; h += step) {
         const uint32_t tri = hard_list[h];
         uint32_t idx[3];
         regular_tri_indices(tri, idx[0], idx[1], idx[2]);
@@ -509,41 +484,51 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// k_scan: exclusive prefix sum of the per-tile counts (one workgroup)
+// k_scan: every raster tile's slice of the bin-entry array, and the tile pass's launch order
 // ---------------------------------------------------------------------------------------
+// A tile needs a slice of `entries` as long as its count - not the slice an ordered prefix sum would give it.  So the
+// scan is local: a workgroup takes 1024 tiles, scans their counts in registers / shuffles / a few words of LDS, and
+// claims the space for all of them with ONE atomic on the frame's entry total; nothing waits for a neighbour.
+// (Round 2: one workgroup of 1024 threads walked the whole frame, 33 us alone and twice that beside the tile pass,
+// whose workgroups left no CU with room for sixteen waves at once.)
 // It also orders the tiles the tile pass will launch over (all of them, or this rank's `cand` list) by falling bin
 // length (eight classes; empty bins - the sky - last): workgroups are handed out in launch order, so the
 // expensive tiles start first and the cheap ones fill the tail of the launch (measured: -2.5 % on the 8K tile pass).
-// One workgroup, two barriers: every thread owns a contiguous chunk of the tile list; chunk sums and per-class tile
-// counts are scanned inside the waves with shuffles and across the sixteen waves through 144 words of LDS.
-// (Round 2's version - 1024 LDS atomics per round on a few histogram words and a twenty-barrier Hillis-Steele scan - took
-// 33 us alone; this one is bounded by its two dependent passes over the counts.)
+// Every class has its own region of `order` (class c from c * stride); a workgroup claims its tiles' places in each
+// with one atomic per class, and the tile pass finds workgroup i's tile from the eight class totals (tile_of_block).
 constexpr int kScanClasses = 8;
+constexpr int kScanPerThread = 4, kScanPerGroup = 256 * kScanPerThread;
 __device__ __forceinline__ int scan_class(uint32_t cnt)
 {
     if (cnt == 0u) return 7;
     const int k = 31 - __clz((int)cnt);                  // floor(log2): >= 256 entries -> 0, 128.. -> 1, 64.. -> 2, 32.. -> 3, 16.. -> 4, 4.. -> 5, 1.. -> 6
     return k >= 8 ? 0 : (k >= 4 ? 8 - k : (k >= 2 ? 5 : 6));
 }
-__global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity,
-                                                const int32_t* __restrict__ cand, int n_cand, int32_t* __restrict__ order)
+__global__ __launch_bounds__(256) void k_scan(int n_tiles, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                               uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ counters, uint32_t capacity,
+                                               const int32_t* __restrict__ cand, int n_cand, int32_t* __restrict__ order)
 {
     VR_GEOMETRY_PRIORITY();
-    __shared__ uint32_t s_wsum[16];                       // per wave: sum of its threads' counts -> exclusive base
-    __shared__ uint32_t s_cls[kScanClasses * 16];         // per (class, wave): tiles of that class -> first slot in `order`
+    constexpr int NW = 4;
+    __shared__ uint32_t s_wsum[NW];                       // per wave: sum of its threads' counts -> first entry of the wave's tiles
+    __shared__ uint32_t s_cls[kScanClasses * NW];         // per (class, wave): tiles of that class -> first place in `order`
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // A rank's bins are the candidates' only (k_setup / k_fill count owned tiles alone): scan that list, not the frame.
     const int n = cand ? n_cand : n_tiles;
-    const int per = (n + 1023) / 1024;
-    const int b = min(tid * per, n), e = min(b + per, n);
+    const int b = min((int)blockIdx.x * kScanPerGroup + tid * kScanPerThread, n), e = min(b + kScanPerThread, n);
+    int t[kScanPerThread]; uint32_t cnt[kScanPerThread];
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) t[j] = b + j < e ? (cand ? cand[b + j] : b + j) : -1;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) cnt[j] = t[j] >= 0 ? tile_count[t[j]] : 0u;
     uint32_t s = 0, cc[kScanClasses];
 #pragma unroll
     for (int c = 0; c < kScanClasses; c++) cc[c] = 0u;
-    for (int i = b; i < e; i++) {
-        const uint32_t cnt = tile_count[cand ? cand[i] : i];
-        s += cnt;
-        const int cl = scan_class(cnt);
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) {
+        if (t[j] < 0) continue;
+        s += cnt[j];
+        const int cl = scan_class(cnt[j]);
 #pragma unroll
         for (int c = 0; c < kScanClasses; c++) cc[c] += cl == c ? 1u : 0u;
     }
@@ -561,49 +546,107 @@ __global__ __launch_bounds__(1024) void k_scan(int n_tiles, uint32_t* __restrict
     if (lane == 63) {
         s_wsum[wave] = incl;
 #pragma unroll
-        for (int c = 0; c < kScanClasses; c++) s_cls[c * 16 + wave] = ci[c];
+        for (int c = 0; c < kScanClasses; c++) s_cls[c * NW + wave] = ci[c];
     }
     __syncthreads();
-    if (wave == 0) {       // exclusive scans of the 16 wave sums and of the 128 (class-major) tile counts, two per lane
-        uint32_t v = lane < 16 ? s_wsum[lane] : 0u, run = v;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { const uint32_t w = (uint32_t)__shfl_up((int)run, d); if (lane >= d) run += w; }
-        if (lane < 16) s_wsum[lane] = run - v;
-        if (lane == 15) {
-            counters[C_BINTOTAL] = run;
-            if (run > capacity) atomicOr(&counters[C_FLAGS], 2u);
-        }
-        const uint32_t a0 = s_cls[2 * lane], a1 = s_cls[2 * lane + 1];
-        uint32_t pr = a0 + a1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t w = (uint32_t)__shfl_up((int)pr, d); if (lane >= d) pr += w; }
-        s_cls[2 * lane] = pr - (a0 + a1); s_cls[2 * lane + 1] = pr - a1;
+    // nine lanes, one quantity each: the workgroup's total (entries / tiles of a class), its share of the frame's (one
+    // atomic), and the four waves' first places
+    if (tid <= kScanClasses) {
+        uint32_t* __restrict__ w = tid < kScanClasses ? &s_cls[tid * NW] : s_wsum;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], total = (w0 + w1) + (w2 + w3);
+        uint32_t base = total ? atomicAdd(&counters[tid < kScanClasses ? C_CLASS0 + tid : C_BINTOTAL], total) : 0u;
+        if (tid == kScanClasses) { if (base + total > capacity) atomicOr(&counters[C_FLAGS], 2u); }
+        else base += (uint32_t)tid * (uint32_t)n_tiles;   // the class's own region of `order`
+        w[0] = base; w[1] = base + w0; w[2] = base + (w0 + w1); w[3] = base + (w0 + w1) + w2;
     }
     __syncthreads();
     uint32_t run = s_wsum[wave] + (incl - s);
     uint32_t slot[kScanClasses];
 #pragma unroll
-    for (int c = 0; c < kScanClasses; c++) slot[c] = s_cls[c * 16 + wave] + (ci[c] - cc[c]);
+    for (int c = 0; c < kScanClasses; c++) slot[c] = s_cls[c * NW + wave] + (ci[c] - cc[c]);
     // the counts are consumed here: zero them for the next frame (saves a memset per frame); the
     // rasteriser gets a bin's length from cursor - offset once k_fill has run
-    for (int i = b; i < e; i++) {
-        const int t = cand ? cand[i] : i;
-        const uint32_t cnt = tile_count[t];
-        tile_offset[t] = run; tile_cursor[t] = run; run += cnt; tile_count[t] = 0u;
-        const int cl = scan_class(cnt);
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) {
+        if (t[j] < 0) continue;
+        tile_offset[t[j]] = run; tile_cursor[t[j]] = run; run += cnt[j]; tile_count[t[j]] = 0u;
+        const int cl = scan_class(cnt[j]);
         uint32_t pos = 0u;
 #pragma unroll
         for (int c = 0; c < kScanClasses; c++) if (cl == c) { pos = slot[c]; slot[c] = pos + 1u; }
-        order[pos] = t;
+        order[pos] = t[j];
     }
+}
+// The tile of the tile pass's workgroup `i`: classes in falling bin length, class c's tiles at order[c * stride ...].
+__device__ __forceinline__ int tile_of_block(int i, const int32_t* __restrict__ order, const uint32_t* __restrict__ class_totals, int stride)
+{
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < kScanClasses - 1; q++) { const int k = (int)class_totals[q]; if (c == q && i >= k) { i -= k; c = q + 1; } }
+    return order[(size_t)c * stride + i];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_setup: regular triangles
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
+                                                uint64_t* __restrict__ rect, uint32_t* __restrict__ hard_list,
+                                                uint32_t* __restrict__ tile_count, uint4* __restrict__ recs)
+{
+    VR_GEOMETRY_PRIORITY();
+    const uint32_t total = counters[C_COUNT] * (uint32_t)kTrisPerInst;
+    for (uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x; tri < total; tri += gridDim.x * blockDim.x) {
+        uint32_t i0, i1, i2;
+        regular_tri_indices(tri, i0, i1, i2);
+        const float4 c0 = *reinterpret_cast<const float4*>(&verts[i0].cx);
+        const float4 c1 = *reinterpret_cast<const float4*>(&verts[i1].cx);
+        const float4 c2 = *reinterpret_cast<const float4*>(&verts[i2].cx);
+        // trivial reject against the six clip planes
+        const bool out_l = (c0.x < -c0.w) && (c1.x < -c1.w) && (c2.x < -c2.w);
+        const bool out_r = (c0.x > c0.w) && (c1.x > c1.w) && (c2.x > c2.w);
+        const bool out_b = (c0.y < -c0.w) && (c1.y < -c1.w) && (c2.y < -c2.w);
+        const bool out_t = (c0.y > c0.w) && (c1.y > c1.w) && (c2.y > c2.w);
+        const bool out_n = (c0.z < 0.0f) && (c1.z < 0.0f) && (c2.z < 0.0f);
+        const bool out_f = (c0.z > c0.w) && (c1.z > c1.w) && (c2.z > c2.w);
+        uint64_t r = ~0ull;
+        if (!(out_l || out_r || out_b || out_t || out_n || out_f)) {
+            const bool need_near = (c0.z < 0.0f) || (c1.z < 0.0f) || (c2.z < 0.0f);
+            const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+            const bool need_guard = (c0.x < -g0) || (c0.x > g0) || (c0.y < -g0) || (c0.y > g0)
+                                 || (c1.x < -g1) || (c1.x > g1) || (c1.y < -g1) || (c1.y > g1)
+                                 || (c2.x < -g2) || (c2.x > g2) || (c2.y < -g2) || (c2.y > g2);
+            if (need_near || need_guard) {
+                const uint32_t slot = atomicAdd(&counters[C_HARDLIST], 1u);
+                if (slot < a.hard_cap) hard_list[slot] = tri; else atomicOr(&counters[C_FLAGS], 2u);
+            } else {
+                r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), recs + (size_t)tri * kRecGroups);
+            }
+        }
+        bin_rect<false>(a, r, 0u, tile_count, nullptr);
+        rect[tri] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_clip: the clipper over the hard list
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__ verts, uint32_t* __restrict__ counters,
+                                              const uint32_t* __restrict__ hard_list, HardTriRec* __restrict__ hard_tris,
+                                              uint32_t* __restrict__ hard_first, uint32_t* __restrict__ tile_count,
+                                              uint4* __restrict__ hard_recs)
+{
+    VR_GEOMETRY_PRIORITY();
+    const uint32_t n_hard = min(counters[C_HARDLIST], a.hard_cap);
+    clip_hard_list(a, verts, counters, hard_list, hard_tris, hard_first, tile_count, hard_recs, blockIdx.x * blockDim.x + threadIdx.x, n_hard,
+                   gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
 // k_fill: write bin entries.  Entry = draw-order key: (triangle id << 4) | (sub << 1) | hard.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __restrict__ counters, const uint64_t* __restrict__ rect,
-                                               const HardTriRec* __restrict__ hard_tris, uint32_t* __restrict__ tile_cursor,
-                                               uint32_t* __restrict__ entries)
+                                               const HardTriRec* __restrict__ hard_tris,
+                                               uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries)
 {
     VR_GEOMETRY_PRIORITY();
     const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
@@ -1119,6 +1162,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
                                                  const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
+                                                 const uint32_t* __restrict__ tile_classes,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
                                                  const float* __restrict__ thr_g,
@@ -1143,7 +1187,7 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     if (a.h < 0) g_diff[0] = lds_pad[tid ^ 1];
 #endif
     VR_PROF_BEGIN;
-    const int tile = tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x;
+    const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
     if (MODE == RM_FAST && tid < kMaxLevels) s_lv[tid] = hm.fast_lv[tid];
 #ifndef VR_EXP_GLOBAL_TABLES
@@ -1325,11 +1369,6 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         }
         VR_PROF_MARK(4);
     }
-#ifdef VR_EXP_LDSREC
-    __shared__ uint4 s_rec[64 * 3];
-    if (tid < 64 * 3 && n > 0 && off < a.bin_capacity)
-        s_rec[tid] = recs[rec_index(entries[off], hard_first, rec_hard_base) * kRecGroups + 5 + tid % 3];
-#endif
     __syncthreads();
     VR_PROF_MARK(5);
 
@@ -1372,42 +1411,74 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
 #define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); \
                               else *reinterpret_cast<u2*>(ptr) = v_; } while (0)
     const bool whole = ox + TILE <= a.w && oy + TILE <= a.h;      // (workgroup-uniform) no pixel of this tile lies outside the target
-    for (int g = tid; g < TILE * TILE / 4; g += kRT) {
+    // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD, and UNCONDITIONALLY: pixel k + 1's record is
+    // requested before pixel k is shaded, so its round trip (entry -> record, a gather: every lane its own triangle) runs
+    // under pixel k's texel fetches instead of in front of pixel k + 1's.  Unconditionally, because a fetch that depends on
+    // "is the next pixel covered" makes the hand-over a merge of two values (the new record, or the one held): the copy
+    // that merge needs waits for EVERYTHING in flight (s_waitcnt vmcnt(0)) - including the five stores the previous pixel
+    // has just issued, whose acknowledgements then sat on every pixel's critical path (no G-buffer stores: -19 % of the
+    // pass; the same bytes into a 256-KB window: no change; profiles/r03_tile_pass_experiments.txt).  An uncovered pixel's
+    // word addresses a record beyond the buffer resource's end and reads zeros.  With a plain hand-over a pixel waits
+    // only for its own record (vmcnt counts in order: the stores and the next record's fetches are younger).
+    // The pipeline runs across the wave's strips as well: the next strip's visibility words are read, and its first record
+    // requested, under the current strip's last pixel.
+    const uint32_t rec_bytes = (rec_hard_base + a.hard_cap * 4u) * (uint32_t)(kRecGroups * 16);      // < 2^32: at most 4096 instances
+    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc((void*)recs, (short)0, (int)rec_bytes, 0x00020000);
+    typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+    struct Rec { u32x4 g5; u3 g6, g7; };
+    auto fetch_rec = [&](uint32_t low) -> Rec {
+        const uint32_t key = key_of(low);
+        uint32_t idx = key >> 4;
+        const bool hard = (key & 1u) != 0u && low != 0xffffffffu;
+        if (__builtin_expect(__any(hard), 0)) {                  // (wave-uniform; clipper output only)
+            if (hard) idx = rec_hard_base + hard_first[idx] + ((key >> 1) & 7u);
+        }
+        const uint32_t off = idx << 7;                           // an uncovered pixel: 0x0fffffff << 7 = far beyond rec_bytes -> zeros
+        Rec r;
+        r.g5 = __builtin_amdgcn_raw_buffer_load_b128(rrec, off, 80, 0);
+        r.g6 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 96, 0);
+        r.g7 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 112, 0);
+        return r;
+    };
+    constexpr int kStrips = TILE * TILE / 4;
+    static_assert(kStrips >= kRT, "every thread owns at least one strip");
+    unsigned long long nkeys[4];
+    {
+        const int lx = tid % TILE, ly0 = (tid / TILE) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) nkeys[k] = vis[(ly0 + k) * TILE + lx];
+    }
+    Rec nrec;                                                     // the NEXT pixel's record
+    if (!depth_only) nrec = fetch_rec((uint32_t)nkeys[0]);
+    else { nrec.g5 = (u32x4){ 0u, 0u, 0u, 0u }; nrec.g6 = (u3){ 0u, 0u, 0u }; nrec.g7 = nrec.g6; }
+    for (int g = tid; g < kStrips; g += kRT) {
         const int lx = g % TILE, ly0 = (g / TILE) * 4;
         const int gx = ox + lx, gy0 = oy + ly0;
-        if (!whole && (gy0 >= a.h || gx >= a.w)) continue;
-        // the column's four visibility words ahead of the per-pixel control flow
-        const unsigned long long keys[4] = { vis[(ly0 + 0) * TILE + lx], vis[(ly0 + 1) * TILE + lx], vis[(ly0 + 2) * TILE + lx], vis[(ly0 + 3) * TILE + lx] };
+        const unsigned long long keys[4] = { nkeys[0], nkeys[1], nkeys[2], nkeys[3] };
+        if (g + kRT < kStrips) {                                  // (uniform) the next strip's visibility words, ahead of this strip's pixels
+            const int ny0 = ((g + kRT) / TILE) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) nkeys[k] = vis[(ny0 + k) * TILE + lx];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) nkeys[k] = ~0ull;
+        }
+        const bool inside = whole || (gy0 < a.h && gx < a.w);     // (per lane) this column lies on the target
         uint32_t pix = (uint32_t)__umul24(gy0, a.w) + (uint32_t)gx;          // < 2^28: both factors below 2^14
 #ifdef VR_EXP_TILED_STORES   // timing experiment only (scrambled image): every tile's pixels contiguous in each plane
-        uint32_t pix4_ = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
+        uint32_t pix4 = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
         const uint32_t w4 = (uint32_t)TILE << 2;
 #else
-        uint32_t pix4_ = pix << 2;                                           // byte offset in a 4-byte plane (a row further: + 4 w)
+        uint32_t pix4 = pix << 2;                                            // byte offset in a 4-byte plane (a row further: + 4 w)
         const uint32_t w4 = (uint32_t)a.w << 2;
 #endif
-        // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD: pixel k + 1's record is requested before pixel
-        // k is shaded, so its round trip (entry -> record, a gather: every lane its own triangle) runs under pixel k's texel
-        // fetches instead of in front of pixel k + 1's.  A pixel's chain of dependent memory accesses - visibility word,
-        // record, finer level, coarser level - is what the resolve waits for (SQ_WAIT_ANY: half of the wave cycles), not the
-        // number of fetches: three albedo fetches fewer per level changed the pass by 1 % (profiles/r03_tile_pass_experiments.txt).
-        // (A record is fetched even when the lane's triangle did not change: a hit in the L1, and no divergent branch.)
-#define COVERED(k_) ((uint32_t)keys[k_] != 0xffffffffu && (whole || gy0 + (k_) < a.h) && !depth_only)
-#ifdef VR_EXP_LDSREC      // timing experiment only (wrong image): every pixel's planes come from an LDS copy of the tile's first record
-#define FETCH_REC(k_, r5_, r6_, r7_) do { const uint4* rp_ = s_rec + ((uint32_t)keys[k_] & 63u) * 3u; r5_ = rp_[0]; r6_ = rp_[1]; r7_ = rp_[2]; } while (0)
-#else
-#define FETCH_REC(k_, r5_, r6_, r7_) do { const uint4* __restrict__ rp_ = recs + rec_index(key_of((uint32_t)keys[k_]), hard_first, rec_hard_base) * kRecGroups; \
-                                          r5_ = rp_[5]; r6_ = rp_[6]; r7_ = rp_[7]; } while (0)
-#endif
-        uint4 n5 = make_uint4(0, 0, 0, 0), n6 = n5, n7 = n5;                 // the NEXT pixel's record
-        if (COVERED(0)) FETCH_REC(0, n5, n6, n7);
 #pragma unroll
-        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4_ += w4) {
+        for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4 += w4) {
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
-            const uint4 g5 = n5, g6 = n6, g7 = n7;                            // this pixel's record (requested one pixel ago)
-            if (k < 3) { if (COVERED(k + 1)) FETCH_REC(k + 1, n5, n6, n7); }
-            if (!whole && gy0 + k >= a.h) continue;
+            const u32x4 g5 = nrec.g5; const u3 g6 = nrec.g6, g7 = nrec.g7;    // this pixel's record (requested one pixel ago)
+            if (!depth_only) nrec = fetch_rec((uint32_t)(k < 3 ? keys[k + 1] : nkeys[0]));
+            if (!inside || (!whole && gy0 + k >= a.h)) continue;
             const bool cov = low != 0xffffffffu;
             if (!cov && !a.assume_cleared) continue;               // keep what the target holds
             const uint32_t dep = (uint32_t)(key >> 32);
@@ -1439,25 +1510,18 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                 else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
 #ifdef VR_EXP_NOSTORE     // timing experiment only: nothing leaves (a dependent dummy keeps the shading alive)
-            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4_, 0, aux);
+            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
             continue;
 #endif
             if (gb_small) {
-#ifdef VR_EXP_STOREWIN    // timing experiment only (wrong image): every store lands in a 256-KB window of its plane - same instructions, no HBM traffic
-                const uint32_t pix4 = pix4_ & 0x3fffcu;
-#else
-                const uint32_t pix4 = pix4_;
-#endif
                 __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
                 if (!depth_only) {
                     const uint32_t pix8 = pix4 + pix4;
                     __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix4, o_diff, aux);
+                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
                     __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
-#if !defined(VR_EXP_NOCONST) && !defined(VR_EXP_WIDECONST)   // timing experiments only (wrong image): the two constant planes are not written / written 16 bytes per lane
-                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
-#endif
                 }
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
@@ -1471,22 +1535,9 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
             }
             VR_PROF_MARK(15);
         }
-#ifdef VR_EXP_WIDECONST   // timing experiment only (uncovered pixels get the covered constant): the strip's constant planes as three 16-byte stores per lane
-        if (gb_small && !depth_only) {
-            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            const u4 sv = { spec_const, spec_const, spec_const, spec_const }, zv4 = { 0u, 0u, 0u, 0u };
-            const uint32_t sp = ((uint32_t)__umul24(gy0 + (lane >> 4), a.w) + (uint32_t)(ox + 4 * (lane & 15))) << 2;
-            __builtin_amdgcn_raw_buffer_store_b128(sv, rgb, sp, o_spec, aux);
-            const uint32_t e0 = ((uint32_t)__umul24(gy0 + (lane >> 5), a.w) + (uint32_t)(ox + 2 * (lane & 31))) << 3;
-            __builtin_amdgcn_raw_buffer_store_b128(zv4, rgb, e0, o_emi, aux);
-            __builtin_amdgcn_raw_buffer_store_b128(zv4, rgb, e0 + ((uint32_t)a.w << 4), o_emi, aux);
-        }
-#endif
     }
 #undef ST1
 #undef ST2
-#undef COVERED
-#undef FETCH_REC
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1571,7 +1622,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
         VR_HIP(hipMalloc(&g.d_tile_count, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&g.d_tile_offset, sizeof(uint32_t) * n_tiles));
         VR_HIP(hipMalloc(&g.d_tile_cursor, sizeof(uint32_t) * n_tiles));
-        VR_HIP(hipMalloc(&g.d_tile_order, sizeof(int32_t) * n_tiles));
+        VR_HIP(hipMalloc(&g.d_tile_order, sizeof(int32_t) * n_tiles * kScanClasses));      // a region per bin-length class
         VR_HIP(hipMemsetAsync(g.d_tile_count, 0, sizeof(uint32_t) * n_tiles, gs));   // k_scan re-zeroes it every frame
         VR_HIP(hipMemsetAsync(g.d_tile_cursor, 0, sizeof(uint32_t) * n_tiles, gs));
         VR_HIP(hipMemsetAsync(g.d_tile_offset, 0, sizeof(uint32_t) * n_tiles, gs));
@@ -1592,8 +1643,11 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
                        g.d_recs + (size_t)t->p.max_instances * kTrisPerInst * kRecGroups); }
     { VrKernelScope ks(ctx, VR_K_SCAN, gs);
     const bool whole = pt == nullptr;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset, g.d_tile_cursor, g.d_counters, a.bin_capacity,
-                       whole ? (const int32_t*)nullptr : (const int32_t*)pt->d_raster_tiles, whole ? n_tiles : pt->num_raster_tiles, g.d_tile_order); }
+    const int n_scan = whole ? n_tiles : pt->num_raster_tiles;
+    if (n_scan > 0)
+        hipLaunchKernelGGL(k_scan, dim3((n_scan + kScanPerGroup - 1) / kScanPerGroup), dim3(256), 0, gs, n_tiles, g.d_tile_count, g.d_tile_offset,
+                           g.d_tile_cursor, g.d_counters, a.bin_capacity, whole ? (const int32_t*)nullptr : (const int32_t*)pt->d_raster_tiles, n_scan,
+                           g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
@@ -1714,7 +1768,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
             ? (a.wireframe ? k_raster<true, 32, RM_GENERIC> : fast ? k_raster<false, 32, RM_FAST> : depth ? k_raster<false, 32, RM_DEPTH> : k_raster<false, 32, RM_GENERIC>)
             : (a.wireframe ? k_raster<true, 64, RM_GENERIC> : fast ? k_raster<false, 64, RM_FAST> : depth ? k_raster<false, 64, RM_DEPTH> : k_raster<false, 64, RM_GENERIC>);
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
-                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles,
+                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
     }

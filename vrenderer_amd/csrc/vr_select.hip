@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
 {
     VR_GEOMETRY_PRIORITY();
     __shared__ uint32_t frontier[2][kFrontLds];
-    __shared__ uint32_t chunk[kRankChunk];
+    __shared__ __attribute__((aligned(16))) uint32_t chunk[kRankChunk];
     __shared__ uint32_t n_front[2], n_sel, overflow;
     uint32_t* __restrict__ spill[2] = { scratch, scratch + (kFrontierCap - kFrontLds) };
     uint32_t* __restrict__ selected = scratch + 2 * (kFrontierCap - kFrontLds);
@@ -116,6 +116,13 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
 #define FR_PUT(buf, i, v) do { if ((i) < (uint32_t)kFrontLds) frontier[buf][i] = (v); else spill[buf][(i) - (uint32_t)kFrontLds] = (v); } while (0)
     const int tid = threadIdx.x;
     const int L = a.num_lods;
+#ifdef VR_SELECT_PROFILE
+    unsigned long long prof_t[6]; int prof_i = 0;
+#define SEL_MARK() do { prof_t[prof_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEL_MARK() do { } while (0)
+#endif
+    SEL_MARK();
     if (tid < a.num_surfaces) frontier[0][tid] = (uint32_t)tid << kPathBits;      // every quadtree's root (at most 64)
     if (tid == 0) { n_front[0] = (uint32_t)a.num_surfaces; n_front[1] = 0u; n_sel = 0u; overflow = 0u; }
     __syncthreads();
@@ -148,7 +155,9 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
             }
             if (select_self) {
                 uint32_t slot = atomicAdd(&n_sel, 1u);
-                if (slot < (uint32_t)kSelectedCap) selected[slot] = ((uint32_t)surf << 26) | ((path << (2 * (L - depth))) << 4) | (uint32_t)depth;
+                const uint32_t skey = ((uint32_t)surf << 26) | ((path << (2 * (L - depth))) << 4) | (uint32_t)depth;
+                if (slot < (uint32_t)kRankChunk) chunk[slot] = skey;          // the first chunk stays in LDS for the rank pass
+                if (slot < (uint32_t)kSelectedCap) selected[slot] = skey;
                 else overflow = 1u;
             }
             if (expand) {
@@ -166,6 +175,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     }
 #undef FR_GET
 #undef FR_PUT
+    SEL_MARK();
 
     // Depth-first order = ascending left-aligned path.  Keys are unique, so a node's rank is the number of smaller
     // keys: the keys stream through LDS a chunk at a time and every thread counts for the (up to 16) keys it owns
@@ -177,21 +187,31 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     const int own_n = (int)((total + kSelThreads - 1) / kSelThreads);        // keys per thread that exist at all (uniform; 2 for ~300 nodes)
     uint32_t key[kOwn], rank[kOwn];
 #pragma unroll
-    for (int o = 0; o < kOwn; o++) { const uint32_t i = (uint32_t)tid + (uint32_t)o * kSelThreads; key[o] = i < total ? selected[i] : 0xffffffffu; rank[o] = 0u; }
+    for (int o = 0; o < kOwn; o++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)o * kSelThreads;
+        key[o] = i < total ? (i < (uint32_t)kRankChunk ? chunk[i] : selected[i]) : 0xffffffffu; rank[o] = 0u;
+    }
     for (uint32_t c0 = 0; c0 < total; c0 += kRankChunk) {
         const uint32_t m = min(total - c0, (uint32_t)kRankChunk);
         __syncthreads();
-        for (uint32_t j = tid; j < m; j += kSelThreads) chunk[j] = selected[c0 + j];
+        // eight keys per step (two 16-byte LDS reads in flight) against every key this thread owns: the pass is bounded by
+        // LDS latency, not by the compares (one key per step: 15 us of the kernel's 37 for 290 nodes)
+        const uint32_t m8 = (m + 7u) & ~7u;                   // (kRankChunk is a multiple of 8)
+        if (c0 == 0u) { for (uint32_t j = tid + m; j < m8; j += kSelThreads) chunk[j] = 0xffffffffu; }          // (already in LDS) pad: counts for no key
+        else for (uint32_t j = tid; j < m8; j += kSelThreads) chunk[j] = j < m ? selected[c0 + j] : 0xffffffffu;
         __syncthreads();
+        for (uint32_t j = 0; j < m8; j += 8) {
+            const uint4 q0 = *reinterpret_cast<const uint4*>(&chunk[j]), q1 = *reinterpret_cast<const uint4*>(&chunk[j + 4]);
 #pragma unroll
-        for (int o = 0; o < kOwn; o++) {
-            if (o >= own_n) break;                                            // (uniform)
-            uint32_t r = 0u;
-            const uint32_t ko = key[o];
-            for (uint32_t j = 0; j < m; j++) r += chunk[j] < ko ? 1u : 0u;
-            rank[o] += r;
+            for (int o = 0; o < kOwn; o++) {
+                if (o >= own_n) break;                                        // (uniform)
+                const uint32_t ko = key[o];
+                rank[o] += (q0.x < ko ? 1u : 0u) + (q0.y < ko ? 1u : 0u) + (q0.z < ko ? 1u : 0u) + (q0.w < ko ? 1u : 0u)
+                         + (q1.x < ko ? 1u : 0u) + (q1.y < ko ? 1u : 0u) + (q1.z < ko ? 1u : 0u) + (q1.w < ko ? 1u : 0u);
+            }
         }
     }
+    SEL_MARK();
 #pragma unroll
     for (int o = 0; o < kOwn; o++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)o * kSelThreads;
@@ -215,6 +235,10 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
         ins.transform[10] = g.ez; ins.transform[11] = g.pz;
         inst[rank[o]] = ins;
     }
+    SEL_MARK();
+#ifdef VR_SELECT_PROFILE
+    if (tid == 0) for (int q = 0; q < 4; q++) { selected[kSelectedCap - 8 + 2 * q] = (uint32_t)prof_t[q]; selected[kSelectedCap - 7 + 2 * q] = (uint32_t)(prof_t[q] >> 32); }
+#endif
     if (tid == 0) {
         counters[0] = limit;
         uint32_t flags = 0;
@@ -637,6 +661,10 @@ extern "C" VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8])
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
     const GeoSet& g = t->sets[t->cur];
     VR_HIP(hipMemcpy(out, g.d_counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+#ifdef VR_SELECT_PROFILE
+    { unsigned long long ts[4]; VR_HIP(hipMemcpy(ts, g.d_sel_scratch + 2 * (kFrontierCap - kFrontLds) + kSelectedCap - 8, sizeof(ts), hipMemcpyDeviceToHost));
+      fprintf(stderr, "k_select cycles: levels %llu  rank %llu  write-out %llu\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]); }
+#endif
     out[6] = 0; out[7] = 0;
     if (g.scratch_tiles > 0 && g.d_tile_cursor) {
         std::vector<uint32_t> c((size_t)g.scratch_tiles), o((size_t)g.scratch_tiles);
