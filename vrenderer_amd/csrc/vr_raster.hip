@@ -1189,13 +1189,27 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
-    if (MODE == RM_FAST && tid < kMaxLevels) s_lv[tid] = hm.fast_lv[tid];
+    // Everything the workgroup needs from memory before its first sweep is requested HERE, at once, and used after the
+    // visibility buffer's set-up: the small tables, the bin's bounds and its first 256 entries (their records follow behind the
+    // barrier: held across it they cost twenty registers and the 32-pixel variant a workgroup per CU).  Written in program order (table, wait, LDS store,
+    // next table, ..., barrier, bounds, entries, records) the prologue was eight dependent round trips per workgroup,
+    // a fifth of a 32-pixel tile's time (4K: init + record fetch = 21 % of the wave cycles).
+    uint4 lv_r = make_uint4(0, 0, 0, 0);
+    if (MODE == RM_FAST && tid < kMaxLevels) lv_r = hm.fast_lv[tid];
 #ifndef VR_EXP_GLOBAL_TABLES
-    if (MODE != RM_FAST && tid < kMaxLevels) { s_qoff[tid] = hm.qoff[tid]; s_aoff[tid] = al.off[tid]; }
-    for (int i = tid; i < (kEncTabSize + 3) / 4; i += kRT) reinterpret_cast<uint32_t*>(enc)[i] = reinterpret_cast<const uint32_t*>(enc_g)[i];
-    if (tid < 256) thr[tid] = thr_g[tid];
-    if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
+    uint32_t qoff_r = 0, aoff_r = 0;
+    if (MODE != RM_FAST && tid < kMaxLevels) { qoff_r = hm.qoff[tid]; aoff_r = al.off[tid]; }
+    constexpr int kEncWords = (kEncTabSize + 3) / 4, kEncPer = (kEncWords + kRT - 1) / kRT;
+    uint32_t enc_r[kEncPer];
+#pragma unroll
+    for (int q = 0; q < kEncPer; q++) enc_r[q] = tid + q * kRT < kEncWords ? reinterpret_cast<const uint32_t*>(enc_g)[tid + q * kRT] : 0u;
+    const float thr_r = tid < 256 ? thr_g[tid] : 0.0f;
 #endif
+    const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
+    // consecutive bin entries go to different waves so that a short list still uses all of them
+    const uint32_t idx0 = (uint32_t)(lane * kRW + wave);
+    const bool valid0 = idx0 < n && (off + idx0) < a.bin_capacity;
+    const uint32_t key0 = valid0 ? entries[off + idx0] : 0u;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
@@ -1214,20 +1228,26 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
         }
         vis[i] = key;
     }
+    if (MODE == RM_FAST && tid < kMaxLevels) s_lv[tid] = lv_r;
+#ifndef VR_EXP_GLOBAL_TABLES
+    if (MODE != RM_FAST && tid < kMaxLevels) { s_qoff[tid] = qoff_r; s_aoff[tid] = aoff_r; }
+#pragma unroll
+    for (int q = 0; q < kEncPer; q++) if (tid + q * kRT < kEncWords) reinterpret_cast<uint32_t*>(enc)[tid + q * kRT] = enc_r[q];
+    if (tid < 256) thr[tid] = thr_r;
+    if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
+#endif
     __syncthreads();
     VR_PROF_MARK(0);
 
-    const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
     const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + TILE - 1, a.vx1), by1 = min(oy + TILE - 1, a.vy1);
     const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
     for (uint32_t base = 0; base < n; base += kRT) {
-        // consecutive bin entries go to different waves so that a short list still uses all of them
-        const uint32_t idx = base + (uint32_t)(lane * kRW + wave);
+        const uint32_t idx = base + idx0;
         bool valid = idx < n && (off + idx) < a.bin_capacity;
-        uint32_t key = 0;
+        uint32_t key = key0;                                   // (the first batch's keys were requested in the prologue)
         uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
         if (valid) {
-            key = entries[off + idx];
+            if (base != 0u) key = entries[off + idx];         // (uniform) the later batches of a long bin
             const uint4* __restrict__ rp = recs + rec_index(key, hard_first, rec_hard_base) * kRecGroups;
             g0 = rp[0]; g1 = rp[1]; g2 = rp[2]; g3 = rp[3]; g4 = rp[4];
         }
