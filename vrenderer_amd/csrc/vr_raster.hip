@@ -1596,6 +1596,11 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     return VR_OK;
 }
 
+// Grids of the three wide geometry kernels (all grid-stride loops).  Fewer, longer workgroups: the chain shares the device
+// with the tile pass, which launches 32 K waves per 8K frame - with 2048 / 4096 / 4096 workgroups the chain launched 41 K of
+// its own.  A/B over the grids (profiles/r03_geometry_grids.txt): 8K frame -0.5..1 %, 4K and the emulated N = 8 rank -2 %;
+// smaller still (128 / 256 / 128) the kernels' own durations double without another gain.
+constexpr int kGridVertex = 512, kGridSetup = 1024, kGridFill = 1024;
 // select -> vertex -> setup -> clip -> scan -> fill into `g`, on the geometry stream
 static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, const vr_view* view, const vr_render_params* rp,
                            const RasterArgs& a, const PartTables* pt)
@@ -1655,9 +1660,9 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
     va.morph_start = t->p.morph_start; va.world_size = t->p.world_size; va.max_height = rp->max_height;
     va.vp_x = a.vp_x; va.vp_y = a.vp_y; va.vp_w = a.vp_w; va.vp_h = a.vp_h;
     { VrKernelScope ks(ctx, VR_K_VERTEX, gs);
-    hipLaunchKernelGGL(k_vertex, dim3(2048), dim3(256), 0, gs, va, t->height, g.d_instances, g.d_counters, g.d_verts); }
+    hipLaunchKernelGGL(k_vertex, dim3(kGridVertex), dim3(256), 0, gs, va, t->height, g.d_instances, g.d_counters, g.d_verts); }
     { VrKernelScope ks(ctx, VR_K_SETUP, gs);
-    hipLaunchKernelGGL(k_setup, dim3(4096), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count, g.d_recs); }
+    hipLaunchKernelGGL(k_setup, dim3(kGridSetup), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count, g.d_recs); }
     { VrKernelScope ks(ctx, VR_K_CLIP, gs);
     hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count,
                        g.d_recs + (size_t)t->p.max_instances * kTrisPerInst * kRecGroups); }
@@ -1669,7 +1674,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
                            g.d_tile_cursor, g.d_counters, a.bin_capacity, whole ? (const int32_t*)nullptr : (const int32_t*)pt->d_raster_tiles, n_scan,
                            g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
+    hipLaunchKernelGGL(k_fill, dim3(kGridFill), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
     g.geo_recorded = true;
     VR_HIP(hipGetLastError());
