@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not build frame i+1's geometry ahead (vr_terrain_prepare) under frame i's tile pass")
+    ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
+                    help="vr_timing_enable level inside the timed region: 2 = dispatch-stamped events on the two big kernels (default), "
+                         "1 = event records around every kernel, 0 = none (no per-kernel figures; measures what the stamps cost)")
     ap.add_argument("--prepare-depth", type=int, default=2, choices=[1, 2],
                     help="how many frames ahead vr_terrain_prepare builds geometry (three geometry sets, one stream each: two chains in flight)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -451,7 +454,7 @@ def main():
     # it: two hipEventRecord calls around each of a frame's dozen small kernels cost the 8K frame 30 us (557 -> 590 us) and
     # make a rank's loop of an 8-way split, whose frame period is near 0.1 ms, host-bound (host 164 us per frame with
     # them, 60 without; tools/exp_host_cost.py).
-    timing_level = 2
+    timing_level = args.timing_level
     ctx.timing_enable(timing_level)
     side_ctxs = [c for c in dict.fromkeys((ctx_comm, ctx_post if use_dist else ctx_comm)) if c is not ctx]
     for c in side_ctxs:

@@ -621,10 +621,21 @@ extern "C" VR_API int vr_partition_prepare(vr_context* ctx, int32_t w, int32_t h
     return vr_partition_tables(ctx, w, h, part, &pt);
 }
 
+// most recently used last: the eviction below (the older half) can then never take a table that an API call in progress
+// has just looked up
+static const PartTables* part_tables_touch(vr_context* ctx, size_t i)
+{
+    PartTables* pt = ctx->part_tables[i];
+    if (i + 1 != ctx->part_tables.size()) { ctx->part_tables.erase(ctx->part_tables.begin() + (long)i); ctx->part_tables.push_back(pt); }
+    return pt;
+}
+
 int vr_partition_slot_tables(vr_context* ctx, int w, int h, int world, const PartTables** out)
 {
-    for (const PartTables* pt : ctx->part_tables)
-        if (pt->w == w && pt->h == h && pt->world == world) { *out = pt; return VR_OK; }
+    for (size_t i = 0; i < ctx->part_tables.size(); i++) {
+        PartTables* pt = ctx->part_tables[i];
+        if (pt->w == w && pt->h == h && pt->world == world) { *out = part_tables_touch(ctx, i); return VR_OK; }
+    }
     const vr_partition p0 = { 0, world };
     return vr_partition_tables(ctx, w, h, &p0, out);
 }
@@ -633,8 +644,10 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
 {
     int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
     VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
-    for (const PartTables* pt : ctx->part_tables)
-        if (pt->w == w && pt->h == h && pt->rank == rank && pt->world == world) { *out = pt; return VR_OK; }
+    for (size_t i = 0; i < ctx->part_tables.size(); i++) {
+        PartTables* pt = ctx->part_tables[i];
+        if (pt->w == w && pt->h == h && pt->rank == rank && pt->world == world) { *out = part_tables_touch(ctx, i); return VR_OK; }
+    }
     VR_HIP(hipSetDevice(ctx->device));
     int tx, ty; owner_grid(w, h, &tx, &ty);
     int max_owned = 0;
@@ -674,6 +687,18 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
     if (!raster.empty() && (e = hipMemcpy(pt->d_raster_tiles, raster.data(), sizeof(int32_t) * raster.size(), hipMemcpyHostToDevice)) != hipSuccess)
         return fail(e, "hipMemcpy(raster tiles)");
     pt->num_owned = (int)owned.size(); pt->max_owned = max_owned; pt->num_raster_tiles = (int)raster.size();
+    // A host that keeps resizing its window (or varies the split) would otherwise grow this cache for as long as the
+    // context lives: beyond 64 keys the older half goes - behind a device-wide wait, since queued kernels may still name
+    // those tables (no caller keeps a PartTables pointer across API calls).
+    if (ctx->part_tables.size() >= 64) {
+        (void)hipDeviceSynchronize();
+        for (size_t i = 0; i < 32; i++) {
+            PartTables* old = ctx->part_tables[i];
+            (void)hipFree(old->d_owned_tiles); (void)hipFree(old->d_tile_slot); (void)hipFree(old->d_raster_tiles);
+            delete old;
+        }
+        ctx->part_tables.erase(ctx->part_tables.begin(), ctx->part_tables.begin() + 32);
+    }
     ctx->part_tables.push_back(pt);
     *out = pt;
     return VR_OK;
