@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -40,7 +41,7 @@ inline int vr_raster_tile_shift(int w, int h, int world = 1)
 {
     const long tiles64 = (long)((w + 63) / 64) * (long)((h + 63) / 64);
     if (world > 1) return tiles64 / world < 1536 ? 5 : 6;
-    return tiles64 < 2560 ? 5 : 6;
+    return tiles64 < 2560 ? 5 : 6;          // (measured again in round 3 with the faster tile pass: 4K with 64-pixel tiles 177 vs 153 us)
 }
 constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
 constexpr int kMaxLevels = 16;
