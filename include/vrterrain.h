@@ -427,6 +427,10 @@ VR_API int vr_synth_albedo(vr_context* ctx, int32_t size, uint32_t seed,
  * [2] clipper sub-triangles, [3] clipper vertices, [4] triangles sent to the clipper, [5] bin entries,
  * [6] largest bin, [7] non-empty bins */
 VR_API int vr_debug_render_stats(vr_terrain* t, uint32_t out[8]);
+/* Test helper: the launch order of the last vr_terrain_render's tile pass - the raster tiles the frame (or this rank) covers,
+ * longest bins first in eight classes (k_scan) - and each of those tiles' bin lengths, in that order.  `capacity` entries per
+ * array; *out_count = number of tiles (0 if nothing was rendered).  Synchronises. */
+VR_API int vr_debug_tile_order(vr_terrain* t, int32_t* out_tiles, uint32_t* out_bin_lengths, int32_t capacity, int32_t* out_count);
 /* Device memory a terrain holds, in bytes: out[0] textures (chains + decoded tables), out[1] per-frame geometry scratch
  * (three rotating sets: instances, vertices, triangle records, bins - sized for params->max_instances), out[2] node
  * heights (after vr_terrain_update_heights), out[3] the sum. */

@@ -1672,3 +1672,41 @@ def test_shadow_fuzz(scene256, oracle, gpu_ctx):
         assert err.max() < 2e-3 and np.sqrt((err ** 2).mean()) <= 1e-4, (it, err.max())
         sm.close()
     hdr.close(); rt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,part", [((1920, 1080), None), ((7680, 4320), None), ((7680, 4320), (3, 8)), ((1000, 700), (1, 2))])
+def test_tile_pass_launch_order_covers_every_tile_once_longest_bins_first(scene2048, gpu_ctx, size, part):
+    """k_scan (workgroup-local scans, one atomic per workgroup and bin-length class): the tile pass's launch order must name
+    every raster tile of the frame - or of this rank's share - exactly once, in classes of falling bin length, and the
+    tiles' slices of the entry array must be disjoint and add up to the frame's entry count."""
+    from vrenderer_amd.scene import flythrough_camera
+    tp = scene2048["tp"]
+    w, h = size
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    v = vr.make_view(*flythrough_camera(40), w, h)
+    p = vr.Partition(*part) if part else None
+    tp.Render(v, v, rt, rp, p)
+    tiles, lens = tp.tile_order()
+    st = tp.render_stats()
+    assert st["flags"] == 0
+    world = part[1] if part else 1
+    # the raster tile edge the library picks (vr_internal.h: vr_raster_tile_shift)
+    tiles64 = ((w + 63) // 64) * ((h + 63) // 64)
+    edge = (32 if tiles64 // world < 1536 else 64) if world > 1 else (32 if tiles64 < 2560 else 64)
+    rtx, rty = (w + edge - 1) // edge, (h + edge - 1) // edge
+    if part:
+        sub = 128 // edge
+        ty, tx = np.divmod(np.arange(rtx * rty), rtx)
+        expect = np.nonzero(((tx // sub + ty // sub) % world) == part[0])[0]
+    else:
+        expect = np.arange(rtx * rty)
+    assert len(tiles) == len(expect)
+    assert np.array_equal(np.sort(tiles), expect), "launch order is not a permutation of the tiles to draw"
+    cls = np.select([lens >= 256, lens >= 128, lens >= 64, lens >= 32, lens >= 16, lens >= 4, lens >= 1], [0, 1, 2, 3, 4, 5, 6], 7)
+    assert (np.diff(cls) >= 0).all(), "bin-length classes out of order"
+    assert int(lens.sum()) == st["bin_entries"]
+    if part is None:                   # (render_stats walks every tile of the target; a rank's chain updates its own tiles' slices only)
+        assert int(lens.max()) == st["max_bin"]
+    rt.close()

@@ -139,7 +139,7 @@ EXPORTS = [
     "vr_shadow_default_params", "vr_shadow_view_setup", "vr_deferred_light_shadowed",
     "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
     "vr_tonemap_add_frame_to_histogram", "vr_tonemap_histogram_device_ptr", "vr_tonemap_compute_exposure", "vr_tonemap_render",
-    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_allgather", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
+    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_allgather", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_tile_order", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
 ]
 
 _lib = None
@@ -245,6 +245,7 @@ def load_library():
         "vr_debug_srgb_encode": (C.c_int, [vp, vp, C.c_size_t, vp]),
         "vr_debug_fastmath_check": (C.c_int, [vp, vp]),
         "vr_debug_render_stats": (C.c_int, [vp, P(C.c_uint32)]),
+        "vr_debug_tile_order": (C.c_int, [vp, vp, vp, C.c_int32, P(C.c_int32)]),
         "vr_debug_download_vertices": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "vr_terrain_memory_bytes": (C.c_int, [vp, P(C.c_uint64)]),
     }

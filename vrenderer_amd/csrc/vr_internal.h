@@ -213,6 +213,7 @@ struct GeoSet {
     int32_t* d_tile_order = nullptr;     // launch order of the tile pass: this frame's tiles by falling bin length
     uint32_t* d_bin_entries = nullptr;
     int scratch_tiles = 0;
+    int last_tiles = 0;                  // raster tiles of the target the last chain was built for (the stride of d_tile_order's class regions)
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;
     hipEvent_t raster_done = nullptr;    // what the geometry stream waits on before reusing this set: ev_raster_done, or the tile pass's own stop event
     uint64_t raster_done_epoch = 0;      // 0: raster_done is this set's own ev_raster_done (always valid); else the context's ev_epoch when the handle was taken

@@ -1653,6 +1653,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
         VR_HIP(hipMemsetAsync(g.d_tile_offset, 0, sizeof(uint32_t) * n_tiles, gs));
         g.scratch_tiles = n_tiles;
     }
+    g.last_tiles = n_tiles;
     VertexArgs va;
     for (int i = 0; i < 16; i++) { va.w2v[i] = view->world_to_view[i]; va.v2c[i] = view->view_to_clip[i]; }
     va.cam_x = view->camera_pos[0]; va.cam_z = view->camera_pos[2];
@@ -1804,5 +1805,36 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     for (GeoSet& p : t->sets)
         if (&p != &g && p.prepared && !p.main_waited && p.geo_recorded) { VR_HIP(hipStreamWaitEvent(s, p.ev_geo_done, 0)); p.main_waited = true; }
     VR_HIP(hipGetLastError());
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_debug_tile_order(vr_terrain* t, int32_t* out_tiles, uint32_t* out_bin_lengths, int32_t capacity, int32_t* out_count)
+{
+    VR_REQUIRE(t && out_tiles && out_bin_lengths && out_count && capacity >= 0, "bad arguments");
+    VR_HIP(hipSetDevice(t->ctx->device));
+    const GeoSet& g = t->sets[t->cur];
+    VR_HIP(hipStreamSynchronize(g.stream));
+    VR_HIP(hipStreamSynchronize(t->ctx->stream));
+    *out_count = 0;
+    const int n_tiles = g.last_tiles;
+    if (n_tiles <= 0 || !g.d_tile_order) return VR_OK;
+    uint32_t cls[kScanClasses];
+    VR_HIP(hipMemcpy(cls, g.d_counters + C_CLASS0, sizeof(cls), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t c : cls) total += c;
+    VR_REQUIRE(total <= (uint64_t)n_tiles && total <= (uint64_t)capacity, "capacity too small for the launch order");
+    std::vector<int32_t> order((size_t)n_tiles * kScanClasses);
+    std::vector<uint32_t> cursor((size_t)n_tiles), offset((size_t)n_tiles);
+    VR_HIP(hipMemcpy(order.data(), g.d_tile_order, order.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(cursor.data(), g.d_tile_cursor, cursor.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VR_HIP(hipMemcpy(offset.data(), g.d_tile_offset, offset.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int c = 0; c < kScanClasses; c++)
+        for (uint32_t i = 0; i < cls[c]; i++) {
+            const int32_t tile = order[(size_t)c * n_tiles + i];
+            VR_REQUIRE(tile >= 0 && tile < n_tiles, "launch order names a tile outside the target");
+            out_tiles[k] = tile; out_bin_lengths[k] = cursor[(size_t)tile] - offset[(size_t)tile]; k++;
+        }
+    *out_count = k;
     return VR_OK;
 }

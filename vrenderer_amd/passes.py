@@ -382,6 +382,14 @@ class TerrainPass:
         keys = ("nodes", "flags", "clip_subtris", "clip_verts", "clipped_tris", "bin_entries", "max_bin", "nonempty_bins")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def tile_order(self, max_tiles=1 << 18):
+        """(tiles, bin_lengths) of the last Render's tile pass in launch order (k_scan: longest bins first, eight classes)."""
+        tiles = np.zeros(max_tiles, np.int32)
+        lens = np.zeros(max_tiles, np.uint32)
+        n = C.c_int32()
+        check(self.ctx.lib.vr_debug_tile_order(self.handle, _vp(tiles), _vp(lens), max_tiles, C.byref(n)), "vr_debug_tile_order")
+        return tiles[:n.value].copy(), lens[:n.value].copy()
+
     def memory_bytes(self):
         """Device memory this terrain holds: dict(textures, scratch, node_heights, total) in bytes."""
         out = (C.c_uint64 * 4)()
