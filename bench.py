@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not build frame i+1's geometry ahead (vr_terrain_prepare) under frame i's tile pass")
+    ap.add_argument("--no-depth-ranges", action="store_true",
+                    help="--lights N: the tiled pass's culling stage reads the depth plane instead of the ranges the tile pass leaves")
     ap.add_argument("--prewarm-laps", type=int, default=1,
                     help="untimed laps of the 120-frame camera path rendered during set-up, before the warm-up steps (device clock ramp)")
     ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
@@ -239,7 +241,9 @@ def main():
     deferred = vr.TiledDeferredLightingPass(ctx) if tiled else vr.DeferredLightingPass(ctx)
     tiled_lights = vr.light_array(lights) if tiled else None        # the vr_light[] the C ABI takes, built once
     light_kernel = "k_deferred_tiled" if tiled else "k_deferred"
-    rp = vr.default_render_params(400.0, assume_cleared=1)   # Clear fused into the tile pass (same result as Clear + Render)
+    # Clear fused into the tile pass (same result as Clear + Render); with the tiled lighting pass behind it, the tile pass also
+    # leaves the light tiles' depth ranges for its culling stage (--no-depth-ranges: the stage reads the depth plane again)
+    rp = vr.default_render_params(400.0, assume_cleared=1, depth_ranges=1 if (tiled and not args.no_depth_ranges) else 0)
 
     shadow_map = None
     if args.shadows:

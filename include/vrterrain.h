@@ -95,7 +95,12 @@ typedef struct vr_render_params {
                                writes clear values itself (fuses RenderTargets::Clear,
                                Renderer.cpp:382)                                     */
     float   max_height;   /* EditorParams::m_MaxHeight = 400                         */
-    int32_t reserved[3];
+    int32_t depth_ranges; /* extension: 1 = leave the depth range of every 32x32 light tile with the G-buffer
+                             (needs assume_cleared, shaded fill mode); vr_deferred_light_tiled's culling
+                             stage then takes them instead of reading the depth plane again.  Any other
+                             write to the G-buffer in between (clear, upload, another render, describe)
+                             drops them; results are identical either way                      */
+    int32_t reserved[2];
 } vr_render_params;
 
 /* Donut LightConstants subset consumed by the deferred pass (ShadeSurface): directional lights

@@ -1710,3 +1710,55 @@ def test_tile_pass_launch_order_covers_every_tile_once_longest_bins_first(scene2
     if part is None:                   # (render_stats walks every tile of the target; a rank's chain updates its own tiles' slices only)
         assert int(lens.max()) == st["max_bin"]
     rt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,part", [((1920, 1080), None), ((7680, 4320), None), ((7680, 4320), (2, 3)), ((7680, 4320), (5, 8))])
+def test_tiled_lighting_with_the_tile_pass_depth_ranges_equals_the_depth_re_read(scene2048, gpu_ctx, size, part):
+    """vr_render_params::depth_ranges: the tile pass leaves every 32x32 light tile's depth range with the G-buffer and the
+    culling stage of the tiled lighting pass takes it instead of reading the depth plane again.  Same minima and maxima ->
+    same light lists -> the lit frame must be identical byte for byte (32- and 64-pixel raster tiles, whole frame and a
+    rank's share); a second lighting call finds the ranges consumed and falls back to the depth plane; a clear in
+    between drops them."""
+    from vrenderer_amd.scene import flythrough_camera
+    from vrenderer_amd.passes import partition_info
+    tp = scene2048["tp"]
+    w, h = size
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    v = vr.make_view(*flythrough_camera(55), w, h)
+    lights = [vr.reference_sun()] + vr.synthetic_point_lights(511, 2048.0, scene2048["h"], 400.0, seed=9001)
+    p = vr.Partition(*part) if part else None
+    if part:
+        info = partition_info(w, h, part[0], part[1])
+        mk = lambda: vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+        dl = lambda im: im.download(info["packed_bytes"])
+    else:
+        mk = lambda: vr.HdrImage(gpu_ctx, w, h)
+        dl = lambda im: im.download()
+    tiled = vr.TiledDeferredLightingPass(gpu_ctx)
+    out = {}
+    for name, flag in (("plain", 0), ("ranges", 1)):
+        img = mk()
+        tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1, depth_ranges=flag), p)
+        tiled.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, img, p)
+        out[name] = dl(img)
+        if flag:                       # the ranges are consumed: this call reads the depth plane
+            tiled.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, img, p)
+            out["again"] = dl(img)
+        img.close()
+    tiled.Status()
+    assert np.array_equal(out["plain"], out["ranges"])
+    assert np.array_equal(out["plain"], out["again"])
+    # stale ranges are never used: render with ranges, clear, render another view without, light
+    img = mk()
+    tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1, depth_ranges=1), p)
+    rt.Clear()
+    v2 = vr.make_view(*flythrough_camera(90), w, h)
+    tp.Render(v2, v2, rt, vr.default_render_params(400.0), p)
+    tiled.Render(v2, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, img, p)
+    a = dl(img)
+    tp.Render(v2, v2, rt, vr.default_render_params(400.0, assume_cleared=1, depth_ranges=1), p)      # (and fresh ones after stale ones)
+    tiled.Render(v2, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, img, p)
+    b = dl(img)
+    assert np.array_equal(a, b)
+    img.close(); rt.close()

@@ -75,7 +75,8 @@ class RenderParams(C.Structure):
         ("depth_only", C.c_int32),
         ("assume_cleared", C.c_int32),
         ("max_height", C.c_float),
-        ("reserved", C.c_int32 * 3),
+        ("depth_ranges", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -553,11 +553,16 @@ __device__ __forceinline__ bool sphere_touches(const float* __restrict__ box, co
     return d2 <= r2;
 }
 
+// RANGES: the light tiles' depth ranges come from the tile pass that rendered the G-buffer (vr_gbuffer::d_ranges: the same
+// minima / maxima of the depths below 1.0, merged with atomics while the pixels were resolved) instead of from a second
+// pass over the depth plane - the kernel's first phase, and most of its time: sixteen 16-byte loads per lane from 512-byte
+// rows 30 KB apart.  The entries are consumed: reset to "none" for the next frame.
+template <bool RANGES>
 __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLight* __restrict__ lights, int num_lights,
                                                      const float* __restrict__ g_depth, int macro_x,
                                                      const int32_t* __restrict__ owned_tiles, uint32_t* __restrict__ lists, int stride,
                                                      int tiles32_x, int tiles32_y, uint32_t* __restrict__ overflow_flag,
-                                                     uint32_t* __restrict__ macro_scratch)
+                                                     uint32_t* __restrict__ macro_scratch, uint2* __restrict__ ranges)
 {
     __shared__ uint32_t s_dmin[kSubTiles], s_dmax[kSubTiles];   // bits of non-negative floats: ordered like the floats
     __shared__ float s_box[kSubTiles + 1][6];                   // the light tiles' boxes, then the macro tile's
@@ -567,9 +572,17 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
     const int tile = owned_tiles ? owned_tiles[blockIdx.x] : (int)blockIdx.x;
     const int ty = tile / macro_x, tx = tile - ty * macro_x;
     const int x0 = tx * kMacroTile, y0 = ty * kMacroTile;
-    if (tid < kSubTiles) { s_dmin[tid] = 0x7f800000u; s_dmax[tid] = 0u; }
+    if (tid < kSubTiles) {
+        uint2 r = make_uint2(0x7f800000u, 0u);
+        if (RANGES) {
+            const int gx = tx * kSubSide + (tid & 3), gy = ty * kSubSide + (tid >> 2);
+            if (gx < tiles32_x && gy < tiles32_y) { uint2* e = ranges + (size_t)gy * tiles32_x + gx; r = *e; *e = make_uint2(0x7f800000u, 0u); }
+        }
+        s_dmin[tid] = r.x; s_dmax[tid] = r.y;
+    }
     if (tid == 0) s_covered = 0u;
     __syncthreads();
+    if (!RANGES) {
     // ---- depth range per light tile: lane = 4 px of a row; a wave holds two rows of the macro tile per step
     const int sub_x = (tid & 31) >> 3;
     // all 16 loads first (a row outside the frame re-reads the frame's first texels and is masked below): one memory
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(256) void k_light_cull(DeferredArgs a, const DevLig
         }
     }
     __syncthreads();
+    }
     // ---- boxes: 8 lanes per cell (its corners: window edges x {dmin, dmax}), reconstructed in the shading pass's exact order
     if (tid < (kSubTiles + 1) * 8) {
         const int b = tid >> 3, corner = tid & 7;
@@ -920,6 +934,12 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         VR_HIP(hipMalloc(&ctx->d_macro_scratch, scratch_words * sizeof(uint32_t)));
         ctx->macro_scratch_words = scratch_words;
     }
+    // The light tiles' depth ranges, if the tile pass that filled this G-buffer left them (for the same split) and nothing has
+    // written to it since.  The culling stage consumes them (every entry it reads is reset), hence CLEAN afterwards - for a
+    // split, only if this rank's share is non-empty (else nothing was written either).
+    const bool use_ranges = gb->ranges_state == vr_gbuffer::RANGES_VALID && gb->d_ranges && gb->ranges_world == (part ? part->world_size : 1)
+                         && gb->ranges_rank == (part ? part->rank : 0);
+    if (use_ranges) gb->ranges_state = vr_gbuffer::RANGES_CLEAN;
     // two launches, each timed under its own id; the shading kernel's events are stamped by its dispatch like the streaming
     // pass's, so its stop event serves as the next frame's geometry start hint (vr_terrain_prepare)
     if (packed) {
@@ -930,8 +950,9 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (pt->num_owned > 0) {
             { VrKernelScope kc(ctx, VR_K_LIGHT_CULL);
-              hipLaunchKernelGGL(k_light_cull, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                                 gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch); }
+              hipLaunchKernelGGL(use_ranges ? k_light_cull<true> : k_light_cull<false>, dim3((unsigned)pt->num_owned), dim3(256), 0, ctx->stream, a, ctx->d_lights,
+                                 num_lights, gb->depth, macro_x, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch,
+                                 gb->d_ranges); }
             VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
             VR_LAUNCH_TIMED(ks, (k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), ctx->stream, a,
                             ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
@@ -940,8 +961,9 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         { VrKernelScope kc(ctx, VR_K_LIGHT_CULL);
-          hipLaunchKernelGGL(k_light_cull, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights, num_lights,
-                             gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch); }
+          hipLaunchKernelGGL(use_ranges ? k_light_cull<true> : k_light_cull<false>, dim3((unsigned)(macro_x * macro_y)), dim3(256), 0, ctx->stream, a, ctx->d_lights,
+                             num_lights, gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch,
+                             gb->d_ranges); }
         VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
         const bool nt = vr_raster_tile_shift(gb->w, gb->h) == 6;      // as in the streaming pass: large frames leave through streaming stores
         if (nt) VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, true>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,

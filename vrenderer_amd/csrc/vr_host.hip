@@ -405,6 +405,7 @@ extern "C" VR_API void vr_gbuffer_destroy(vr_gbuffer* g)
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipFree(g->depth);   // base of the single allocation
+    (void)hipFree(g->d_ranges);
     delete g;
 }
 
@@ -436,6 +437,7 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
 {
     VR_REQUIRE(g != nullptr, "gbuffer is NULL");
     VR_HIP(hipSetDevice(g->ctx->device));
+    vr_gbuffer_touch(g);
     size_t n = (size_t)g->w * g->h;
     hipStream_t s = g->ctx->stream;
     int rc;
@@ -448,9 +450,31 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
     return VR_OK;
 }
 
+__global__ void k_fill_u32x2(uint2* p, size_t n, uint32_t x, uint32_t y)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint2(x, y);
+}
+int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s)
+{
+    const int tiles = ((g->w + 31) / 32) * ((g->h + 31) / 32);
+    if (!g->d_ranges || g->ranges_tiles != tiles) {
+        VR_HIP(hipStreamSynchronize(s));
+        (void)hipFree(g->d_ranges); g->d_ranges = nullptr; g->ranges_state = vr_gbuffer::RANGES_NONE;
+        VR_HIP(hipMalloc(&g->d_ranges, (size_t)tiles * sizeof(uint2)));
+        g->ranges_tiles = tiles;
+    }
+    if (g->ranges_state != vr_gbuffer::RANGES_CLEAN) {
+        hipLaunchKernelGGL(k_fill_u32x2, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, g->d_ranges, (size_t)tiles, 0x7f800000u, 0u);
+        VR_HIP(hipGetLastError());
+        g->ranges_state = vr_gbuffer::RANGES_CLEAN;
+    }
+    return VR_OK;
+}
+
 extern "C" VR_API int vr_gbuffer_describe(vr_gbuffer* g, vr_gbuffer_desc* d)
 {
     VR_REQUIRE(g && d, "NULL argument");
+    vr_gbuffer_touch(g);           // the caller gets the device pointers: whatever it writes through them is unknown here
     d->width = g->w; d->height = g->h; d->depth = g->depth; d->diffuse = g->diffuse; d->specular = g->specular;
     d->normals = g->normals; d->emissive = g->emissive;
     return VR_OK;
@@ -485,6 +509,7 @@ extern "C" VR_API int vr_gbuffer_upload(vr_gbuffer* g, int plane, const void* ho
     void* p; size_t nb; int rc = plane_info(g, plane, &p, &nb); if (rc) return rc;
     VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
     VR_HIP(hipSetDevice(g->ctx->device));
+    vr_gbuffer_touch(g);
     VR_HIP(hipMemcpyAsync(p, host, nb, hipMemcpyHostToDevice, g->ctx->stream));
     VR_HIP(hipStreamSynchronize(g->ctx->stream));
     return VR_OK;

@@ -175,7 +175,18 @@ struct vr_gbuffer {
     vr_context* ctx;
     int w, h;
     float* depth; uint32_t* diffuse; uint32_t* specular; uint2* normals; uint2* emissive;
+    // Depth range (bits of the smallest / largest depth below 1.0) of every 32x32 light tile, left behind by a tile pass that
+    // was asked for it (vr_render_params::depth_ranges) and consumed - and reset to "none" = (0x7f800000, 0) - by the tiled
+    // lighting pass's culling stage, which then need not read the depth plane a second time.
+    uint2* d_ranges = nullptr;
+    int ranges_tiles = 0;
+    enum { RANGES_NONE = 0, RANGES_CLEAN, RANGES_VALID, RANGES_DIRTY };
+    int ranges_state = RANGES_NONE;          // CLEAN: every entry "none"; VALID: the last writer of the G-buffer left them; DIRTY: stale
+    int ranges_rank = 0, ranges_world = 1;   // the screen-tile split they were rendered for
 };
+// (anything else that writes the G-buffer: its depth ranges are stale)
+inline void vr_gbuffer_touch(vr_gbuffer* g) { if (g->ranges_state == vr_gbuffer::RANGES_VALID) g->ranges_state = vr_gbuffer::RANGES_DIRTY; }
+int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s);      // allocated and every entry "none" (vr_host.hip)
 
 struct vr_image {
     vr_context* ctx;

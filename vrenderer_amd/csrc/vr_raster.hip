@@ -1156,7 +1156,8 @@ constexpr int kRT = VR_RASTER_THREADS, kRW = kRT / 64;
 //   RM_DEPTH   depth only (the shadow map's pass): no record fetch, no texel fetch, one store per pixel;
 //   RM_GENERIC everything else, decided at run time.
 enum { RM_GENERIC = 0, RM_FAST = 1, RM_DEPTH = 2 };
-template <bool WIRE, int TILE, int MODE>
+// RANGES (fast variant only): the depth range of every 32x32 light tile is left at `ranges` for the tiled lighting pass.
+template <bool WIRE, int TILE, int MODE, bool RANGES = false>
 __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
@@ -1166,8 +1167,9 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
                                                  const float* __restrict__ thr_g,
-                                                 const uint8_t* __restrict__ enc_g, uint32_t spec_const)
+                                                 const uint8_t* __restrict__ enc_g, uint32_t spec_const, uint2* __restrict__ ranges)
 {
+    static_assert(!RANGES || MODE == RM_FAST, "depth ranges come with the fast variant");
     __shared__ unsigned long long vis[TILE * TILE];
 #ifdef VR_EXP_GLOBAL_TABLES   // experiment: the small tables read from global memory, so that a 64-pixel tile's workgroup needs exactly 32 KB of LDS (5 per CU)
     const uint8_t* __restrict__ enc = enc_g;
@@ -1471,6 +1473,8 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     Rec nrec;                                                     // the NEXT pixel's record
     if (!depth_only) nrec = fetch_rec((uint32_t)nkeys[0]);
     else { nrec.g5 = (u32x4){ 0u, 0u, 0u, 0u }; nrec.g6 = (u3){ 0u, 0u, 0u }; nrec.g7 = nrec.g6; }
+    // RANGES: smallest / largest depth bits below 1.0 this lane has seen in the upper / lower 32 rows of the tile
+    uint32_t rmin0 = 0x7f800000u, rmax0 = 0u, rmin1 = 0x7f800000u, rmax1 = 0u;
     for (int g = tid; g < kStrips; g += kRT) {
         const int lx = g % TILE, ly0 = (g / TILE) * 4;
         const int gx = ox + lx, gy0 = oy + ly0;
@@ -1503,6 +1507,10 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
             if (!cov && !a.assume_cleared) continue;               // keep what the target holds
             const uint32_t dep = (uint32_t)(key >> 32);
             uint32_t dif = 0, nn0 = 0, nn1 = 0;
+            if (RANGES && cov && dep < 0x3f800000u) {
+                if (TILE == 64 && ly0 >= 32) { rmin1 = min(rmin1, dep); rmax1 = max(rmax1, dep); }       // (wave-uniform: a strip lies in one half)
+                else { rmin0 = min(rmin0, dep); rmax0 = max(rmax0, dep); }
+            }
             VR_PROF_MARK(8);
             if (cov && !depth_only) {
                 const float q0 = __uint_as_float(g5.x), qx = __uint_as_float(g5.y), qy = __uint_as_float(g5.z);
@@ -1554,6 +1562,22 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
                 }
             }
             VR_PROF_MARK(15);
+        }
+    }
+    if (RANGES) {
+        // lanes that share a light tile: the 32-lane halves of a wave (64-pixel tiles: neighbouring columns) or the whole wave
+        // (32-pixel tiles: two rows of one tile); one lane per light tile merges the wave's range into the G-buffer's
+#pragma unroll
+        for (int off = 1; off <= (TILE == 64 ? 16 : 32); off <<= 1) {
+            rmin0 = min(rmin0, (uint32_t)__shfl_xor((int)rmin0, off)); rmax0 = max(rmax0, (uint32_t)__shfl_xor((int)rmax0, off));
+            if (TILE == 64) { rmin1 = min(rmin1, (uint32_t)__shfl_xor((int)rmin1, off)); rmax1 = max(rmax1, (uint32_t)__shfl_xor((int)rmax1, off)); }
+        }
+        if ((lane & (TILE == 64 ? 31 : 63)) == 0) {
+            const int tiles32_x = (a.w + 31) >> 5;
+            const int ltx = (ox >> 5) + (TILE == 64 ? lane >> 5 : 0), lty = oy >> 5;
+            // (a range exists only where a covered pixel does, i.e. inside the frame: the index is valid)
+            if (rmin0 <= rmax0) { uint2* r = ranges + (size_t)lty * tiles32_x + ltx; atomicMin(&r->x, rmin0); atomicMax(&r->y, rmax0); }
+            if (TILE == 64 && rmin1 <= rmax1) { uint2* r = ranges + (size_t)(lty + 1) * tiles32_x + ltx; atomicMin(&r->x, rmin1); atomicMax(&r->y, rmax1); }
         }
     }
 #undef ST1
@@ -1790,12 +1814,20 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
                            && (const char*)gb->depth < (const char*)gb->normals && (const char*)gb->depth < (const char*)gb->emissive && span < (1ull << 32);
         const bool fast = same && a.ws_pow2 && one_rsrc && !a.wireframe && !a.depth_only;
         const bool depth = a.depth_only && !a.wireframe;
+        // the light tiles' depth ranges, if asked for: only from the fast variant over a target it fills completely
+        const bool ranges = rp->depth_ranges && fast && a.assume_cleared;
+        if (ranges) {
+            if ((rc = vr_gbuffer_ranges_prepare(gb, s))) return rc;
+            gb->ranges_state = vr_gbuffer::RANGES_VALID; gb->ranges_rank = a.rank; gb->ranges_world = a.world;
+        } else vr_gbuffer_touch(gb);
         auto kern = a.tile_shift == 5
-            ? (a.wireframe ? k_raster<true, 32, RM_GENERIC> : fast ? k_raster<false, 32, RM_FAST> : depth ? k_raster<false, 32, RM_DEPTH> : k_raster<false, 32, RM_GENERIC>)
-            : (a.wireframe ? k_raster<true, 64, RM_GENERIC> : fast ? k_raster<false, 64, RM_FAST> : depth ? k_raster<false, 64, RM_DEPTH> : k_raster<false, 64, RM_GENERIC>);
+            ? (a.wireframe ? k_raster<true, 32, RM_GENERIC> : ranges ? k_raster<false, 32, RM_FAST, true> : fast ? k_raster<false, 32, RM_FAST>
+               : depth ? k_raster<false, 32, RM_DEPTH> : k_raster<false, 32, RM_GENERIC>)
+            : (a.wireframe ? k_raster<true, 64, RM_GENERIC> : ranges ? k_raster<false, 64, RM_FAST, true> : fast ? k_raster<false, 64, RM_FAST>
+               : depth ? k_raster<false, 64, RM_DEPTH> : k_raster<false, 64, RM_GENERIC>);
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0,
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const);
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
     }
     if (pass_stop) { g.raster_done = pass_stop; g.raster_done_epoch = ctx->ev_epoch; }
