@@ -591,7 +591,8 @@ def main():
                     "avg_us": round(avg_s * 1e6, 2), "bytes_per_launch": bytes_per_px * px,
                     "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"
                             + ("; a kernel that only moves the same bytes reaches 5.6-5.9 TB/s on this part (profiles/r01_stream_layout_ceiling.txt)"
-                               if name == "k_deferred" else "; instruction-issue bound, see roofline_valu and DESIGN.md 4")}
+                               if name == "k_deferred" else "; runs at ~80 % of the per-CU memory pipeline (fetches and stores in series) and at half of a store-only kernel's rate, "
+                                    "see write_stream_ceiling, roofline_l1, roofline_valu and DESIGN.md 4")}
 
         def roof_valu(name):
             """Vector-instruction issue of the tile pass / the tiled lighting pass.  achieved = wave-instructions per launch
