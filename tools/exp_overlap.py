@@ -9,7 +9,9 @@ import vrenderer_amd as vr
 from vrenderer_amd.scene import params, AMBIENT_TOP, AMBIENT_BOTTOM, flythrough_camera
 W, H, size = 7680, 4320, 2048
 torch.cuda.set_device(0)
-s_main, s_light = torch.cuda.Stream(), torch.cuda.Stream()
+PRIO = os.environ.get("PRIO", "none")      # none | main (tile pass on a high-priority stream) | light (lighting pass on one)
+s_main = torch.cuda.Stream(priority=-1 if PRIO == "main" else 0)
+s_light = torch.cuda.Stream(priority=-1 if PRIO == "light" else 0)
 ctx = vr.Context(0); ctx.set_stream(s_main.cuda_stream)
 ctx2 = vr.Context(0); ctx2.set_stream(s_light.cuda_stream)
 hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
@@ -42,4 +44,4 @@ def run(overlap, n):
 for overlap in (False, True, False, True):
     run(overlap, 10)
     t0 = time.perf_counter(); run(overlap, 120); dt = time.perf_counter() - t0
-    print("two frames in flight" if overlap else "one frame at a time ", "%.1f us per frame = %.1f Gpixels/s" % (dt / 120 * 1e6, W * H * 120 / dt / 1e9), flush=True)
+    print("prio", PRIO, "two frames in flight" if overlap else "one frame at a time ", "%.1f us per frame = %.1f Gpixels/s" % (dt / 120 * 1e6, W * H * 120 / dt / 1e9), flush=True)
