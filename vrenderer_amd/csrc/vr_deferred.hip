@@ -485,9 +485,8 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
         if (gb->w % 4 == 0) {
             const size_t quads = npx / 4;
-            // frames whose G-buffer + HdrColor traffic exceeds the Infinity Cache (the ones the tile pass runs on 64-pixel tiles
-            // and writes with streaming stores, vr_internal.h) leave through streaming stores here as well
-            const bool nt = vr_raster_tile_shift(gb->w, gb->h) == 6;
+            // streaming loads and stores at every frame size, like the tile pass's stores (vr_raster.hip: measured per size)
+            const bool nt = true;
             auto kern = shadow ? (nt ? k_deferred<false, true, true, true> : k_deferred<false, true, true, false>)
                                : extra ? (nt ? k_deferred<false, true, false, true> : k_deferred<false, true, false, false>)
                                        : (nt ? k_deferred<false, false, false, true> : k_deferred<false, false, false, false>);
@@ -965,7 +964,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
                              num_lights, gb->depth, macro_x, (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, ty, ctx->d_flags, ctx->d_macro_scratch,
                              gb->d_ranges); }
         VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
-        const bool nt = vr_raster_tile_shift(gb->w, gb->h) == 6;      // as in the streaming pass: large frames leave through streaming stores
+        const bool nt = true;                                         // as in the streaming pass
         if (nt) VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, true>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,
                                 gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
                                 (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);

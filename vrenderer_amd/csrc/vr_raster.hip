@@ -1417,21 +1417,21 @@ __global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterAr
     // did when a lane owned four pixels of a row.
     // Every pixel leaves through its stores as soon as it is shaded (nothing is kept for the end of the column): a wave's
     // store covers 64 (32) neighbouring pixels of a row, 256 contiguous bytes per 4-byte plane.
-    // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass 0.6 ms later.
-    // Kept out of the caches it does not sit there as 256 MB of dirty lines that the lighting pass then has to evict
-    // while it streams (measured: k_deferred 226 -> 213 us, 66 -> 70 % of the HBM roofline; tile pass unchanged).
-    // Frames that use the 32-pixel tiles (< 16.7 M pixels, < 470 MB) mostly fit the cache and are written normally.
-    // (Compile-time choice: a run-time branch between the two store flavours gets merged and loses the hint.)
+    // Streaming (non-temporal) stores: the G-buffer is written once and read once by the lighting pass.  Kept out of the
+    // caches it does not sit there as dirty lines that the lighting pass has to evict while it streams (8K: k_deferred
+    // 226 -> 213 us), and - with the lighting pass streaming as well - the NEXT tile pass still finds its 180 MB of texel
+    // tables in the Infinity Cache.  Round 2 made the choice by frame size (64-pixel tiles only: "smaller frames mostly fit
+    // the cache"); measured again with this round's tile pass, streaming both passes wins or ties at every size: 4K frame
+    // 0.223 -> 0.204 ms (tile pass 148 -> 123 us), 1440p 0.152 -> 0.148, 1080p and 720p unchanged (profiles/r03_nontemporal_sizes.txt).
     // The five planes of a vr_gbuffer are one allocation: one buffer resource, the plane as the scalar offset and one
     // 32-bit pixel offset per store instead of a 64-bit address per plane and pixel.
     // The hot path is kept free of taken branches: everything the fast variant knows is a template parameter, the implicit
     // LOD is computed with selects, and the two rare cases (a reciprocal outside the short sequence's range, a second mip
     // level) sit behind wave-uniform branches that fall through when they do not apply.
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-    constexpr int aux = TILE == 64 ? 2 : 0;               // nt
-#define ST1(ptr, v) do { if (TILE == 64) __builtin_nontemporal_store((v), (ptr)); else *(ptr) = (v); } while (0)
-#define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; if (TILE == 64) __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); \
-                              else *reinterpret_cast<u2*>(ptr) = v_; } while (0)
+        constexpr int aux = 2;                                // nt (every frame size: measured again in round 3, below)
+#define ST1(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define ST2(ptr, a_, b_) do { u2 v_ = { (a_), (b_) }; __builtin_nontemporal_store(v_, reinterpret_cast<u2*>(ptr)); } while (0)
     const bool whole = ox + TILE <= a.w && oy + TILE <= a.h;      // (workgroup-uniform) no pixel of this tile lies outside the target
     // The winner's planes (record groups 5..7) are fetched ONE PIXEL AHEAD, and UNCONDITIONALLY: pixel k + 1's record is
     // requested before pixel k is shaded, so its round trip (entry -> record, a gather: every lane its own triangle) runs
