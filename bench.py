@@ -457,6 +457,10 @@ def main():
     # clocks; the W = 5 warm-up frames of the driver's command are 3 ms.  Measured on one box, the same 20 frames:
     # 0.584-0.590 ms per frame straight after 5 warm-up frames, 0.547-0.550 ms after a lap (profiles/r03_clock_ramp.txt).
     # Disclosed in the line ("untimed_setup"); --prewarm-laps 0 gives the raw figure.
+    import gc
+    gc.collect(); gc.disable()               # no collector pause while the host queues the warm-up and timed frames (20 frames are 11 ms);
+                                             # here, not between warm-up and timed region: a collection there idles the device for tens of
+                                             # milliseconds and the timed frames then measure its clock ramp (0.54 -> 0.61 ms, measured)
     for i in range(120 * args.prewarm_laps):
         step(i)
     sync()
@@ -476,8 +480,6 @@ def main():
         c.timing_enable(timing_level)
     if use_dist:
         xch_timed[0] = True
-    import gc
-    gc.collect(); gc.disable()               # no collector pause while the host queues the timed frames (20 frames are 11 ms)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
