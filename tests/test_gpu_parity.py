@@ -1615,7 +1615,9 @@ def test_api_sequence_fuzz(oracle, gpu_ctx):
                 continue
             part = vr.Partition(int(rng.integers(0, 3)), 3) if op in ("part", "part_prepared") else None
             lock = op == "lock" and can_lock
-            rp = vr.default_render_params(400.0, assume_cleared=1, lock_view=int(lock))
+            # (depth_ranges: the tile pass variant that also leaves the light tiles' depth ranges - never consumed here, so its
+            # clean / valid / dirty bookkeeping runs through every transition; the G-buffer must not change)
+            rp = vr.default_render_params(400.0, assume_cleared=1, lock_view=int(lock), depth_ranges=int(step % 3 == 1))
             if op in ("prepare_render", "part_prepared"):
                 tp.Prepare(v, rt, rp, part)
             elif op == "prepare_other":
