@@ -31,17 +31,20 @@ constexpr int kVertsPerInst = kSide * kSide; // 1089
 constexpr int kTrisPerInst = kGrid * kGrid * 2; // 2048
 constexpr int kRecGroups = 8;                // 16-byte groups per triangle record (vr_raster.hip: write_tri_rec)
 constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of large frames; also the upper bound of either size
-// Tile edge of the raster / bin grid for a w x h target: 64, or 32 when 64-pixel tiles would leave the chip's
-// 1024 workgroup slots short of work (measured in round 2, 64- vs 32-pixel tiles: 1080p tile pass 144 vs 91 us, 1440p 152 vs
-// 116, 4K 190 vs 188, 5120x2880 253 vs 270, 8K far apart the other way): the switch sits just above 4K's 2040 tiles.
-// A rank of an N-way split rasterises 1/N of the tiles, scattered over a frame whose triangles stay large: 32-pixel
-// tiles pay there only once the share drops below ~1.5 launch waves (measured at 8K on one GPU: N=2 274 vs 391 us,
-// N=4 153 vs 192 us with 64- vs 32-pixel tiles, N=8 107 vs 83 us).
+// Tile edge of the raster / bin grid for a w x h target: 64, or 32 when this rank draws fewer than kTile64Min 64-pixel
+// tiles.  A 64-pixel tile amortises the per-workgroup work (tables, bin header, barrier) over four times the pixels and
+// sweeps a triangle of the 8K frame (30-60 pixels) in one or two tiles instead of four; 32-pixel tiles are four times as
+// many workgroups (launch waves, tail) and five instead of four of them fit a CU.  Measured again in the second session of
+// round 3 with that round's tile pass, frame time of the bench, 64- vs 32-pixel tiles: 4K 0.248 vs 0.231 ms, 5120x2880
+// 0.312 vs 0.287, 6400x3600 0.414 vs 0.404, 7040x3960 0.475 vs 0.475, 8K 0.541 vs 0.552; a rank of an N-way split of the
+// 8K frame (tile pass alone in brackets): N = 2 0.400 vs 0.378 ms, N = 4 0.232 vs 0.210 (149 vs 124 us), N = 8 0.154 vs 0.130
+// (profiles/r03_tile_size_thresholds.txt).  Round 2's thresholds - 2560 tiles for the whole frame, 1536 per rank -
+// came from a tile pass that was 40 % slower per pixel and cost N = 2 and N = 4 5-10 %.
+constexpr long kTile64Min = 6800;
 inline int vr_raster_tile_shift(int w, int h, int world = 1)
 {
     const long tiles64 = (long)((w + 63) / 64) * (long)((h + 63) / 64);
-    if (world > 1) return tiles64 / world < 1536 ? 5 : 6;
-    return tiles64 < 2560 ? 5 : 6;          // (measured again in round 3 with the faster tile pass: 4K with 64-pixel tiles 177 vs 153 us)
+    return tiles64 / (world > 1 ? world : 1) < kTile64Min ? 5 : 6;
 }
 constexpr int kMaxLights = 16;               // terrain_cb.h:15 / Donut DEFERRED_MAX_LIGHTS
 constexpr int kMaxLevels = 16;
