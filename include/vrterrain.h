@@ -135,7 +135,7 @@ typedef struct vr_gbuffer_desc {
 /* Screen-tile partition of one frame over the GPUs of a node. */
 #define VR_OWNER_TILE 128
 typedef struct vr_partition {
-    int32_t rank, world_size;   /* owner(tx,ty) = (tx + ty) mod world_size        */
+    int32_t rank, world_size;   /* owner(tx,ty) = (tx + ty) mod world_size; 1 <= world_size <= 64 */
 } vr_partition;
 
 typedef struct vr_context  vr_context;

@@ -45,6 +45,7 @@ struct RasterArgs {
     int tile_shift;                 // log2 of the raster tile edge (5 or 6)
     int mirrored;
     int world, rank;                // partition (world <= 1: whole frame)
+    uint32_t world_magic;           // ceil(2^16 / world): (v * magic) >> 16 == v / world for the owner-tile sums v < 1024 (world <= 64)
     int depth_only, assume_cleared;
     int wireframe;                  // RasterFillMode::Wireframe: triangle edges as aliased lines
     float world_size, inv_world_size;
@@ -236,7 +237,10 @@ __device__ __forceinline__ bool tile_owned(const RasterArgs& a, int tx, int ty)
 {
     if (a.world <= 1) return true;
     const int sub_shift = 7 - a.tile_shift;                     // VR_OWNER_TILE = 128 = raster tile << sub_shift
-    return (((tx >> sub_shift) + (ty >> sub_shift)) % a.world) == a.rank;
+    // (tx + ty) % world without the ~40-instruction division by a run-time value: on 32-pixel tiles most triangles of a large
+    // frame touch several tiles and this test runs per tile in three kernels
+    const uint32_t v = (uint32_t)((tx >> sub_shift) + (ty >> sub_shift));
+    return v - ((v * a.world_magic) >> 16) * (uint32_t)a.world == (uint32_t)a.rank;
 }
 
 __device__ __forceinline__ uint64_t pack_rect(int tx0, int ty0, int tx1, int ty1)
@@ -1611,6 +1615,8 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     a.tile_shift = vr_raster_tile_shift(w, h, world);
     { const int rt = 1 << a.tile_shift; a.rtx = (w + rt - 1) / rt; a.rty = (h + rt - 1) / rt; }
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
+    VR_REQUIRE(world <= 64, "at most 64 ranks");                 // (the owner-tile test's reciprocal multiplication is exact up to there)
+    a.world_magic = (65536u + (uint32_t)world - 1u) / (uint32_t)world;
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared; a.wireframe = rp->wireframe ? 1 : 0;
     a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
     { uint32_t wb; memcpy(&wb, &t->p.world_size, 4); a.ws_pow2 = (wb & 0x7fffffu) == 0u && t->p.world_size >= 1.0f && t->p.world_size <= 65536.0f; }
