@@ -1162,7 +1162,13 @@ constexpr int kRT = VR_RASTER_THREADS, kRW = kRT / 64;
 enum { RM_GENERIC = 0, RM_FAST = 1, RM_DEPTH = 2 };
 // RANGES (fast variant only): the depth range of every 32x32 light tile is left at `ranges` for the tiled lighting pass.
 template <bool WIRE, int TILE, int MODE, bool RANGES = false>
-__global__ __launch_bounds__(kRT, VR_RASTER_WAVES_PER_EU) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
+// A 32-pixel tile's workgroup needs 11 KB of LDS: registers, not LDS, decide how many fit a CU.  Asked for six waves per SIMD
+// the compiler fits every 32-pixel variant into 80 VGPRs without a spill (84-90 otherwise: five waves): 5120x2880 frame
+// 0.288 -> 0.279 ms, 4K 0.203 -> 0.2015, the rank of an 8-way split 0.128 -> 0.126 (profiles/r03_tile32_waves.txt).
+#ifndef VR_RASTER_WAVES_32
+#define VR_RASTER_WAVES_32 6
+#endif
+__global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_WAVES_PER_EU)) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
