@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--fixed-camera", action="store_true", help="reference default camera instead of the flythrough")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not build frame i+1's geometry ahead (vr_terrain_prepare) under frame i's tile pass")
+    ap.add_argument("--raster-tile", type=int, default=0, choices=[0, 32, 64],
+                    help="pin the tile pass's raster tile edge (VR_OPT_RASTER_TILE); 0 = by frame size and split (default)")
     ap.add_argument("--no-depth-ranges", action="store_true",
                     help="--lights N: the tiled pass's culling stage reads the depth plane instead of the ranges the tile pass leaves")
     ap.add_argument("--prewarm-laps", type=int, default=1,
@@ -225,6 +227,8 @@ def main():
 
     W, H, size = args.width, args.height, args.size
     ctx = vr.Context(local_rank)
+    if args.raster_tile:
+        ctx.set_raster_tile(args.raster_tile)
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -511,8 +515,25 @@ def main():
             c.timing_enable(False)
         for k, v in diag.items():
             timings.setdefault(k, v)
+        # ... and the geometry chain with the device to itself: beside the tile pass its kernels' durations are residence times
+        # (below ~9.6K x 5.4K the tile pass runs six waves of 80 VGPRs per SIMD and leaves a geometry wave 32), not costs
+        chain_alone = None
+        if shadow_map is None:
+            try:
+                ctx.timing_enable(1)
+                for i in range(8):
+                    tp.Prepare(views[(args.warmup + args.steps + extra + 31 + 13 * i) % 120], rt, rp, part)
+                    ctx.synchronize()
+                alone = ctx.timing_collect()
+                ctx.timing_enable(False)
+                chain_alone = {k: round(ms / n * 1e3, 2) for k, (ms, n) in alone.items()
+                               if k in ("k_select", "k_vertex", "k_setup", "k_clip", "k_scan", "k_fill")}
+            except Exception:
+                chain_alone = None
         kernels_note = (f"k_raster and the lighting kernel from the {args.steps} timed frames (dispatch-stamped events); every other kernel from "
-                        f"{extra} further frames timed with events around every launch, outside the timed region")
+                        f"{extra} further frames timed with events around every launch, outside the timed region - beside the tile pass, "
+                        "whose waves leave the geometry kernels few registers: their figures there are residence times, "
+                        "geometry_chain_alone_us has them with the device to themselves")
     n_nodes = tp.num_chunks()
     if tiled:
         deferred.Status()            # raises if a tile kept more than VR_TILE_LIGHT_CAP lights (the result would be truncated)
@@ -681,6 +702,8 @@ def main():
         }
         if kernels_note:
             out["kernels_note"] = kernels_note
+            if chain_alone:
+                out["geometry_chain_alone_us"] = dict(chain_alone, sum=round(sum(chain_alone.values()), 1))
         if emu:
             out["emulation"] = {"rank": args.emulate_rank, "world": args.emulate_world, "owned_pixels": owned_px,
                                 "what": "one GPU computes this rank's share of the N-way screen-tile split per frame (geometry replicated, "

@@ -156,7 +156,9 @@ VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submi
 /* VR_OPT_DISPATCH_EVENTS (default 1): the two big kernels of a frame (tile pass, lighting pass) are launched with
  * hipExtLaunchKernelGGL, whose start/stop events are stamped by the dispatch itself, and the stop events double as the
  * cross-stream dependencies - no event-record packets sit between the two kernels.  0 = explicit hipEventRecord. */
-enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2 };
+/* VR_OPT_RASTER_TILE (default 0): edge of the tile pass's raster tiles - 0 = chosen by frame size and split (32 pixels below
+ * ~13000 64-pixel tiles per rank, i.e. up to about 9.6K x 5.4K; 64 above), 32 or 64 = pinned.  The rendered frame does not depend on it. */
+enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE = 3 };
 VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);

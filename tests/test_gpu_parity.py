@@ -1696,7 +1696,7 @@ def test_tile_pass_launch_order_covers_every_tile_once_longest_bins_first(scene2
     world = part[1] if part else 1
     # the raster tile edge the library picks (vr_internal.h: vr_raster_tile_shift)
     tiles64 = ((w + 63) // 64) * ((h + 63) // 64)
-    edge = 32 if tiles64 // world < 6800 else 64
+    edge = 32 if tiles64 // world < 13000 else 64
     rtx, rty = (w + edge - 1) // edge, (h + edge - 1) // edge
     if part:
         sub = 128 // edge
@@ -1767,53 +1767,90 @@ def test_tiled_lighting_with_the_tile_pass_depth_ranges_equals_the_depth_re_read
 
 
 @pytest.mark.gpu
-def test_split_of_a_12k_frame_on_64_pixel_tiles_reassembles_to_the_unsplit_frame(scene2048, gpu_ctx):
-    """A rank draws 64-pixel raster tiles only when its share is 6800 of them or more (vr_internal.h): no split of an 8K
-    frame is that large any more.  12288x6912 split three ways is (6912 tiles per rank): the packed lit tiles of the three
-    ranks, de-tiled, must equal the unsplit frame byte for byte, and so must every rank's G-buffer planes on its own
-    tiles.  (Whole frames on 64-pixel tiles are compared with the oracle at 8K; this keeps the partitioned path of that
-    variant - candidate lists in the scan, owner-tile launch order, packed lighting - under test.)"""
+@pytest.mark.parametrize("edge", [64, 32])
+def test_split_of_the_8k_frame_reassembles_to_the_unsplit_frame_on_either_tile_size(scene2048, gpu_ctx, edge):
+    """The raster tile edge follows the frame size and the split (32 pixels up to ~9.6K x 5.4K, vr_internal.h); either can be
+    pinned (VR_OPT_RASTER_TILE).  With each pinned in turn: the packed lit tiles of a 3-way split of the 8K frame, de-tiled,
+    must equal the unsplit frame (rendered on the OTHER tile size) byte for byte, and so must every rank's G-buffer planes on
+    its own tiles - candidate lists in the scan, owner-tile launch order, packed lighting of both variants."""
     from vrenderer_amd.scene import flythrough_camera
     from vrenderer_amd.passes import frame_detile, partition_info
     tp = scene2048["tp"]
-    W, H, world = 12288, 6912, 3
-    assert ((W + 63) // 64) * ((H + 63) // 64) // world >= 6800
+    W, H, world = 7680, 4320, 3
     v = vr.make_view(*flythrough_camera(17), W, H)
     rt = vr.RenderTargets(gpu_ctx).Init(W, H)
     rp = vr.default_render_params(400.0, assume_cleared=1)
     lights = [vr.reference_sun()]
     dl = vr.DeferredLightingPass(gpu_ctx)
-    full = vr.HdrImage(gpu_ctx, W, H)
-    tp.Render(v, v, rt, rp)
-    tiles, lens = tp.tile_order()
-    assert len(tiles) == ((W + 63) // 64) * ((H + 63) // 64)            # 64-pixel tiles
-    dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, full)
-    ref = full.download()
-    ref_depth = rt.download("depth").view(np.uint32)
-    ref_nrm = rt.download("normals")
-    full.close()
-    info = partition_info(W, H, 0, world)
-    gathered = np.zeros(world * info["packed_bytes"] // 2, np.uint16)
-    ty, tx = np.divmod(np.arange((H // 128) * (W // 128)), W // 128)
-    for r in range(world):
-        part = vr.Partition(r, world)
-        packed = vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+    try:
+        gpu_ctx.set_raster_tile(96 - edge)                                    # the unsplit reference on the other tile size
+        full = vr.HdrImage(gpu_ctx, W, H)
+        tp.Render(v, v, rt, rp)
+        tiles, _ = tp.tile_order()
+        assert len(tiles) == ((W + 95 - edge) // (96 - edge)) * ((H + 95 - edge) // (96 - edge))
+        dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, full)
+        ref = full.download()
+        ref_depth = rt.download("depth").view(np.uint32)
+        ref_nrm = rt.download("normals")
+        full.close()
+        gpu_ctx.set_raster_tile(edge)
+        info = partition_info(W, H, 0, world)
+        gathered = np.zeros(world * info["packed_bytes"] // 2, np.uint16)
+        oh, ow = (H + 127) // 128, W // 128
+        ty, tx = np.divmod(np.arange(oh * ow), ow)
+        pad = oh * 128 - H
+        def owner_tiles(a):
+            a = np.pad(a, ((0, pad),) + ((0, 0),) * (a.ndim - 1))
+            return a.reshape((oh, 128, ow, 128) + a.shape[2:]).swapaxes(1, 2)
+        for r in range(world):
+            part = vr.Partition(r, world)
+            packed = vr.HdrImage(gpu_ctx, 128, info["max_owned"] * 128)
+            rt.Clear()
+            tp.Render(v, v, rt, rp, part)
+            t_r, _ = tp.tile_order()
+            assert 0 < len(t_r) < len(tiles) * (96 - edge) ** 2 // edge ** 2          # a share of the tiles of this size
+            dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, packed, part)
+            gathered[r * info["packed_bytes"] // 2:(r + 1) * info["packed_bytes"] // 2] = packed.download(info["packed_bytes"])
+            packed.close()
+            own = ((tx + ty) % world == r).reshape(oh, ow)
+            assert np.array_equal(owner_tiles(rt.download("depth").view(np.uint32))[own], owner_tiles(ref_depth)[own])
+            assert np.array_equal(owner_tiles(rt.download("normals"))[own], owner_tiles(ref_nrm)[own])
+        big = vr.HdrImage(gpu_ctx, 128, world * info["max_owned"] * 128)
+        big.upload(gathered)
+        out = vr.HdrImage(gpu_ctx, W, H)
+        frame_detile(gpu_ctx, big.device_ptr, world, out)
+        assert np.array_equal(out.download(), ref)
+        big.close(); out.close()
+    finally:
+        gpu_ctx.set_raster_tile(0)
+        rt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("edge", [32, 64])
+@pytest.mark.parametrize("size,part", [((1280, 720), None), ((1000, 700), None), ((1000, 700), (1, 3))])
+def test_both_tile_sizes_bit_exact_against_the_oracle(scene2048, oracle, gpu_ctx, edge, size, part):
+    """Every G-buffer plane against the oracle with the raster tile edge pinned to 32 and to 64 pixels (VR_OPT_RASTER_TILE), whole
+    frame and a rank's share, at sizes the oracle renders in a fraction of a second - the frame size picks only one of the two
+    variants, and since round 3's re-measured rule the 64-pixel one only beyond ~9.6K x 5.4K."""
+    from vrenderer_amd.scene import flythrough_camera
+    w, h = size
+    v = vr.make_view(*flythrough_camera(83), w, h)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    p = vr.Partition(*part) if part else None
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    try:
+        gpu_ctx.set_raster_tile(edge)
+        gb_o = oracle.GBufferHost(w, h)
+        n_o = scene2048["ot"].render(v, gb_o, rp, p)
         rt.Clear()
-        tp.Render(v, v, rt, rp, part)
-        t_r, _ = tp.tile_order()
-        assert len(t_r) * world == len(tiles)                              # its third of the 64-pixel tiles
-        dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, packed, part)
-        gathered[r * info["packed_bytes"] // 2:(r + 1) * info["packed_bytes"] // 2] = packed.download(info["packed_bytes"])
-        packed.close()
-        d = rt.download("depth").view(np.uint32).reshape(H // 128, 128, W // 128, 128)
-        n = rt.download("normals").reshape(H // 128, 128, W // 128, 128, -1)
-        own = ((tx + ty) % world == r).reshape(H // 128, W // 128)
-        assert np.array_equal(d.transpose(0, 2, 1, 3)[own], ref_depth.reshape(H // 128, 128, W // 128, 128).transpose(0, 2, 1, 3)[own])
-        assert np.array_equal(n.transpose(0, 2, 1, 3, 4)[own], ref_nrm.reshape(H // 128, 128, W // 128, 128, -1).transpose(0, 2, 1, 3, 4)[own])
-    big = vr.HdrImage(gpu_ctx, 128, world * info["max_owned"] * 128)
-    big.upload(gathered)
-    out = vr.HdrImage(gpu_ctx, W, H)
-    frame_detile(gpu_ctx, big.device_ptr, world, out)
-    assert np.array_equal(out.download(), ref)
-    for o in (big, out, rt):
-        o.close()
+        scene2048["tp"].Render(v, v, rt, rp, p)
+        assert scene2048["tp"].num_chunks() == n_o
+        tiles, _ = scene2048["tp"].tile_order()
+        if part is None:
+            assert len(tiles) == ((w + edge - 1) // edge) * ((h + edge - 1) // edge)
+        planes = {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+        _assert_gbuffer_equal(gb_o, planes, f"{w}x{h}, {edge}-pixel tiles, partition {part}")
+    finally:
+        gpu_ctx.set_raster_tile(0)
+        rt.close()

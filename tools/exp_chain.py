@@ -12,6 +12,7 @@ import vrenderer_amd as vr
 from vrenderer_amd.scene import params, flythrough_camera
 size = 2048
 ctx = vr.Context(0); ctx.set_async_geometry(False)
+if os.environ.get("TILE"): ctx.set_raster_tile(int(os.environ["TILE"]))      # pin the raster tile edge (32 / 64)
 hm = vr.synth_heightmap(ctx, size); al = vr.synth_albedo(ctx, size, hm)
 tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
 for (W, H) in ((1920, 1080), (3840, 2160), (7680, 4320)):

@@ -24,6 +24,7 @@ VR_K_COUNT = 18
 VR_TONEMAP_BINS = 256
 VR_OPT_ASYNC_GEOMETRY = 1
 VR_OPT_DISPATCH_EVENTS = 2
+VR_OPT_RASTER_TILE = 3
 
 
 class TerrainParams(C.Structure):

@@ -97,8 +97,12 @@ extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
 extern "C" VR_API int vr_context_set_option(vr_context* c, int option, int value)
 {
     VR_REQUIRE(c != nullptr, "ctx is NULL");
-    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS, "unknown option");
+    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS || option == VR_OPT_RASTER_TILE, "unknown option");
     if (option == VR_OPT_ASYNC_GEOMETRY) c->async_geometry = value != 0;
+    else if (option == VR_OPT_RASTER_TILE) {
+        VR_REQUIRE(value == 0 || value == 32 || value == 64, "VR_OPT_RASTER_TILE: 0 (by size), 32 or 64");
+        c->raster_tile_force = value == 32 ? 5 : value == 64 ? 6 : 0;
+    }
     else { VR_HIP(hipStreamSynchronize(c->stream)); c->dispatch_events = value != 0; c->last_stop = nullptr; }
     return VR_OK;
 }
@@ -669,9 +673,10 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
 {
     int world = part ? part->world_size : 1, rank = part ? part->rank : 0;
     VR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad partition");
+    const int tile_shift = vr_raster_tile_shift(w, h, world, ctx->raster_tile_force);
     for (size_t i = 0; i < ctx->part_tables.size(); i++) {
         PartTables* pt = ctx->part_tables[i];
-        if (pt->w == w && pt->h == h && pt->rank == rank && pt->world == world) { *out = part_tables_touch(ctx, i); return VR_OK; }
+        if (pt->w == w && pt->h == h && pt->rank == rank && pt->world == world && pt->tile_shift == tile_shift) { *out = part_tables_touch(ctx, i); return VR_OK; }
     }
     VR_HIP(hipSetDevice(ctx->device));
     int tx, ty; owner_grid(w, h, &tx, &ty);
@@ -679,7 +684,7 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
     for (int r = 0; r < world; r++) { int c = count_owned(tx, ty, r, world); if (c > max_owned) max_owned = c; }
     std::vector<int32_t> owned, slot((size_t)tx * ty), raster;
     std::vector<int> next(world, 0);
-    const int rtile = 1 << vr_raster_tile_shift(w, h, world);
+    const int rtile = 1 << tile_shift;
     const int rtx = (w + rtile - 1) / rtile, rty = (h + rtile - 1) / rtile;
     const int sub = VR_OWNER_TILE / rtile;
     for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++) {
@@ -694,7 +699,7 @@ int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part,
         }
     }
     PartTables* pt = new PartTables();
-    pt->w = w; pt->h = h; pt->rank = rank; pt->world = world;
+    pt->w = w; pt->h = h; pt->rank = rank; pt->world = world; pt->tile_shift = tile_shift;
     auto fail = [&](hipError_t e, const char* what) {
         vr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, what, hipGetErrorString(e));
         (void)hipFree(pt->d_owned_tiles); (void)hipFree(pt->d_tile_slot); (void)hipFree(pt->d_raster_tiles);

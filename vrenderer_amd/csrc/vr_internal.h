@@ -39,10 +39,15 @@ constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of larg
 // 0.312 vs 0.287, 6400x3600 0.414 vs 0.404, 7040x3960 0.475 vs 0.475, 8K 0.541 vs 0.552; a rank of an N-way split of the
 // 8K frame (tile pass alone in brackets): N = 2 0.400 vs 0.378 ms, N = 4 0.232 vs 0.210 (149 vs 124 us), N = 8 0.154 vs 0.130
 // (profiles/r03_tile_size_thresholds.txt).  Round 2's thresholds - 2560 tiles for the whole frame, 1536 per rank -
-// came from a tile pass that was 40 % slower per pixel and cost N = 2 and N = 4 5-10 %.
-constexpr long kTile64Min = 6800;
-inline int vr_raster_tile_shift(int w, int h, int world = 1)
+// came from a tile pass that was 40 % slower per pixel and cost N = 2 and N = 4 5-10 %.  With the 32-pixel variants at six waves
+// per SIMD (vr_raster.hip) they win up to ~9.6K x 5.4K: 8K 0.544 vs 0.527 ms, 7040x3960 0.472 vs 0.455, 9600x5400 0.796 vs 0.792,
+// 12288x6912 1.250 vs 1.265 - hence 13000.
+constexpr long kTile64Min = 13000;
+// `force`: 0 = the rule above, 5 / 6 = 32- / 64-pixel tiles whatever the size (vr_context_set_option(VR_OPT_RASTER_TILE): tests
+// compare both variants with the oracle at sizes the oracle finishes in seconds; a host may pin the choice)
+inline int vr_raster_tile_shift(int w, int h, int world = 1, int force = 0)
 {
+    if (force == 5 || force == 6) return force;
     const long tiles64 = (long)((w + 63) / 64) * (long)((h + 63) / 64);
     return tiles64 / (world > 1 ? world : 1) < kTile64Min ? 5 : 6;
 }
@@ -111,6 +116,7 @@ static_assert(sizeof(HardTriRec) == 32, "HardTriRec layout");
 // Screen-tile partition of a w x h frame for one rank of `world`: built once, immutable afterwards.
 struct PartTables {
     int w = 0, h = 0, rank = 0, world = 1;
+    int tile_shift = 0;                 // raster tile edge the table of raster tiles was built for (part of the cache key)
     int32_t* d_owned_tiles = nullptr;   // owner-tile ids (128x128) owned by this rank
     int32_t* d_tile_slot = nullptr;     // per owner tile: rank * max_owned + local index
     int32_t* d_raster_tiles = nullptr;  // raster-tile ids (64x64 or 32x32) inside owned owner tiles
@@ -130,6 +136,7 @@ struct vr_context {
     // shadow map's and the main view's geometry every frame)
     std::vector<PartTables*> part_tables;
     bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
+    int raster_tile_force = 0;     // VR_OPT_RASTER_TILE: 0 = by size (vr_raster_tile_shift), 5 / 6 = 32- / 64-pixel raster tiles
     // VR_OPT_DISPATCH_EVENTS: the tile pass and the lighting pass are launched with hipExtLaunchKernelGGL, whose start/stop
     // events are stamped by the dispatch itself; the stop events double as the cross-stream dependencies (tile pass done ->
     // its geometry set is free; lighting pass done -> the next frame's geometry may start), so no event-record packets

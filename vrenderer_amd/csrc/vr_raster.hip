@@ -1618,7 +1618,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     if (a.vy0 < 0) a.vy0 = 0;
     if (a.vx1 > w - 1) a.vx1 = w - 1;
     if (a.vy1 > h - 1) a.vy1 = h - 1;
-    a.tile_shift = vr_raster_tile_shift(w, h, world);
+    a.tile_shift = vr_raster_tile_shift(w, h, world, t->ctx->raster_tile_force);
     { const int rt = 1 << a.tile_shift; a.rtx = (w + rt - 1) / rt; a.rty = (h + rt - 1) / rt; }
     a.mirrored = view->mirrored; a.world = world; a.rank = rank;
     VR_REQUIRE(world <= 64, "at most 64 ranks");                 // (the owner-tile test's reciprocal multiplication is exact up to there)

@@ -40,6 +40,10 @@ class Context:
         """Geometry stages of TerrainPass.Render on a second stream (overlaps the previous frame's lighting)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_ASYNC_GEOMETRY, int(enable)), "vr_context_set_option")
 
+    def set_raster_tile(self, edge):
+        """Edge of the tile pass's raster tiles: 0 = by frame size and split (default), 32 or 64 = pinned."""
+        check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_RASTER_TILE, int(edge)), "vr_context_set_option")
+
     def set_dispatch_events(self, enable):
         """Tile pass / lighting pass launched with dispatch-stamped events that double as cross-stream dependencies (default on)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_DISPATCH_EVENTS, int(enable)), "vr_context_set_option")
