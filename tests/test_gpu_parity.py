@@ -1840,6 +1840,8 @@ def test_both_tile_sizes_bit_exact_against_the_oracle(scene2048, oracle, gpu_ctx
     p = vr.Partition(*part) if part else None
     rt = vr.RenderTargets(gpu_ctx).Init(w, h)
     try:
+        gpu_ctx.set_raster_tile(96 - edge)
+        scene2048["tp"].Prepare(v, rt, rp, p)          # geometry prepared for the OTHER tile size must not be taken for this frame
         gpu_ctx.set_raster_tile(edge)
         gb_o = oracle.GBufferHost(w, h)
         n_o = scene2048["ot"].render(v, gb_o, rp, p)

@@ -253,7 +253,7 @@ struct GeoSet {
     // vr_terrain_prepare: geometry already built for exactly these inputs
     bool prepared = false;
     uint64_t prep_serial = 0;            // order of the vr_terrain_prepare calls (the oldest prepared set is evicted first)
-    vr_view prep_view; vr_render_params prep_rp; int prep_w = 0, prep_h = 0, prep_rank = 0, prep_world = 0;
+    vr_view prep_view; vr_render_params prep_rp; int prep_w = 0, prep_h = 0, prep_rank = 0, prep_world = 0, prep_tile_shift = 0;
 };
 
 struct vr_terrain {

@@ -1721,7 +1721,8 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
 static bool prepared_matches(const GeoSet& g, const vr_view* view, const vr_render_params* rp, int w, int h, const RasterArgs& a)
 {
     return memcmp(&g.prep_view, view, sizeof(vr_view)) == 0 && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only
-        && !g.prep_rp.wireframe == !rp->wireframe && g.prep_w == w && g.prep_h == h && g.prep_rank == a.rank && g.prep_world == a.world;
+        && !g.prep_rp.wireframe == !rp->wireframe && g.prep_w == w && g.prep_h == h && g.prep_rank == a.rank && g.prep_world == a.world
+        && g.prep_tile_shift == a.tile_shift;      // (VR_OPT_RASTER_TILE may have changed in between: the bins are per tile size)
 }
 
 static int check_render_inputs(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp)
@@ -1769,7 +1770,7 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     for (const GeoSet& p : t->sets) other_prepared |= (&p != &g) && p.prepared;
     if (other_prepared) g.main_waited = false;
     else { VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0)); g.main_waited = true; }
-    g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world;
+    g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world; g.prep_tile_shift = a.tile_shift;
     g.prep_serial = ++t->prep_counter;
     return VR_OK;
 }
