@@ -162,6 +162,9 @@ enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE
 VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);
+/* 0 for a product build.  Non-zero: the library was built with timing-experiment or profiling switches
+ * (csrc/vr_experiments.h: -DVR_EXPERIMENT_BUILD + VR_EXP_* / VR_*_PROFILE) and may render wrong images on purpose. */
+VR_API uint32_t vr_build_experiments(void);
 
 /* Per-kernel timing with HIP events recorded on the context's stream, the analogue of
  * the reference's PROFILE_GPU_SCOPE timestamp queries (Profiler.h:55-125,

@@ -30,6 +30,9 @@ def build(force=False):
     """Builds the oracle library (with -mfma: the model's fmaf() calls become one instruction).  On a host without FMA
     hardware the same source is built without the flag into its own file - libm's fmaf gives the identical values."""
     global LIB_PATH
+    if os.environ.get("VR_ORACLE_LIB"):           # an instrumented build of the same source (oracle/Makefile: asan), already built
+        LIB_PATH = os.environ["VR_ORACLE_LIB"]
+        return LIB_PATH
     src = os.path.join(_DIR, "vr_oracle.c")
     nofma = not _host_has_fma()
     if nofma:
@@ -44,7 +47,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH) or not _host_has_fma():
+    if not os.path.exists(LIB_PATH) or not _host_has_fma() or os.environ.get("VR_ORACLE_LIB"):
         build()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER

@@ -131,6 +131,26 @@ def test_product_never_imports_the_oracle():
                 assert "vr_oracle" not in text and "pyoracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
 
 
+def test_product_build_has_no_experiment_switch():
+    """Timing experiments that render wrong images on purpose (VR_EXP_*) and instrumented kernels live behind
+    csrc/vr_experiments.h and -DVR_EXPERIMENT_BUILD: the library the tests and the bench load was built with none of them,
+    the kernel sources test constexpr flags instead of the preprocessor, and the product's compiler flags define nothing."""
+    lib = capi.load_library()
+    assert lib.vr_build_experiments() == 0
+    csrc = os.path.join(ROOT, "vrenderer_amd", "csrc")
+    for f in os.listdir(csrc):
+        text = open(os.path.join(csrc, f), errors="ignore").read()
+        if f == "vr_experiments.h":
+            assert "#error" in text and "VR_EXPERIMENT_BUILD" in text
+            continue
+        assert "VR_EXP_" not in text and "VR_LDS_PAD" not in text, f"{f}: experiment switches belong in vr_experiments.h"
+        if f.endswith(".hip") and ("VR_RASTER_PROFILE" in text or "VR_SELECT_PROFILE" in text):
+            assert '#include "vr_experiments.h"' in text, f"{f}: profiling switches are guarded by vr_experiments.h"
+    from vrenderer_amd import build as b
+    flags = list(b.FLAGS) + [x for v in b.PER_FILE_FLAGS.values() for x in v]
+    assert not any(x.startswith("-DVR_") for x in flags), flags
+
+
 def test_pack_detile_roundtrip_numpy():
     rng = np.random.default_rng(3)
     for (w, h, world) in ((300, 260, 3), (512, 256, 2), (130, 70, 8)):

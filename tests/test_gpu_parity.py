@@ -1058,6 +1058,36 @@ def test_prepared_geometry_is_equivalent(scene256, oracle, gpu_ctx):
     rt.close()
 
 
+def test_context_stream_changed_between_prepare_and_render(scene2048, oracle, gpu_ctx):
+    """vr_context_set_stream between vr_terrain_prepare and vr_terrain_render (per-stage streams): the wait
+    for the prepared chain that prepare queued sits on the OLD stream; the tile pass on the new one must wait for the chain
+    itself, or it reads vertices, bins and records that the geometry kernels are still writing."""
+    import torch
+    ot, tp = scene2048["ot"], scene2048["tp"]
+    w, h = 960, 540
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    gpu_ctx.synchronize()                                 # (the new target's clear ran on the stream the context had until now)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        for k, cam in enumerate((CAMERAS[0], CAMERAS[3], CAMERAS[5])):
+            v = vr.make_view(*cam, w, h)
+            gb = oracle.GBufferHost(w, h)
+            gb.clear(); ot.render(v, gb, rp)
+            first, second = (sa, sb) if k % 2 == 0 else (sb, sa)
+            gpu_ctx.set_stream(first.cuda_stream)
+            tp.Prepare(v, rt, rp)                         # geometry on the terrain's stream; the context's stream (first) waits for it
+            second.wait_stream(first)                     # what the host owes: its own work on the old stream is ordered before the new one
+            gpu_ctx.set_stream(second.cuda_stream)
+            tp.Render(v, v, rt, rp)                       # ... but the chain itself is the library's to wait for
+            planes = {p: rt.download(p) for p in ("depth", "diffuse", "specular", "normals", "emissive")}
+            _assert_gbuffer_equal(gb, planes, f"stream switched between prepare and render, camera {k}")
+    finally:
+        torch.cuda.synchronize()
+        gpu_ctx.set_stream(0)
+        rt.close()
+
+
 def test_deferred_spot_and_spherical_lights(scene256, oracle, gpu_ctx):
     """All three Donut light types through the streaming pass (ShadeSurface: cone falloff by
     1 - smoothstep(inner, outer, angle), spherical sources with a per-pixel half angle)."""

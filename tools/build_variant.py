@@ -8,6 +8,9 @@ sys.path.insert(0, ROOT)
 from vrenderer_amd import build as B  # noqa: E402
 
 name, extra = sys.argv[1], sys.argv[2:]
+# switches that change the image or instrument a kernel only compile in an experiment build (csrc/vr_experiments.h)
+if any(f.split("=", 1)[-1].startswith(("-DVR_EXP_", "-DVR_RASTER_PROFILE", "-DVR_SELECT_PROFILE")) for f in extra) and "-DVR_EXPERIMENT_BUILD" not in extra:
+    extra = extra + ["-DVR_EXPERIMENT_BUILD"]
 out = os.path.join(B.LIB_DIR, "variants", name)
 os.makedirs(out, exist_ok=True)
 objs = []

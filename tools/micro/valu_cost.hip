@@ -2,6 +2,10 @@
 // tile pass's resolve is made of, at 1 / 2 / 4 / 5 waves per SIMD, eight independent chains per wave.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/valu_cost.hip -o tools/micro/valu_cost
 // Output feeds DESIGN.md 4 ("what the vector pipes can issue") and bench.py's roofline_valu.peak.
+// Round 4 (calibration): every figure is now derived THREE ways - from s_memtime ticks of the median wave (as before), from the
+// kernel's wall time (HIP events) at the shader clock the same launch measured (s_memtime / s_memrealtime x 100 MHz), and
+// checked against a census of where the waves really ran (HW_ID: waves per SIMD) - because round 3's table showed v_fma_f64
+// and v_pk_fma_f32 at twice the datasheet's vector peak.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -23,6 +27,7 @@ static const char* kNames[M_COUNT] = { "v_mul_f32", "v_add_f32", "v_fma_f32 (a*s
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, float s, int iters)
 {
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
     const double ds = s;
@@ -130,7 +135,17 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, fl
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+        cyc[w] = t1 - t0;
+        cyc[nw + w] = rt1 - rt0;                                             // 100 MHz ticks over the same interval (+ prologue)
+        // where this wave ran: XCC id, and HW_ID's SE / SH / CU / SIMD fields (wave slot, queue and VM ids masked off)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        cyc[2 * nw + w] = ((unsigned long long)(xcc & 0xfu) << 16) | (hw & 0xff30u);
+        cyc[3 * nw + w] = t0;                                                // start stamp: were all waves resident at once?
+        cyc[4 * nw + w] = t1;
+    }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7)
         + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p5.x + p6.x + p7.x;
 }
@@ -143,27 +158,65 @@ int main()
 {
     kern_t tab[M_COUNT]; Tab<M_COUNT - 1>::fill(tab);
     float* d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
-    unsigned long long* c; hipMalloc(&c, 256 * 8 * 4 * sizeof(unsigned long long));
-    std::vector<unsigned long long> h(256 * 8 * 4);
+    unsigned long long* c; hipMalloc(&c, 5 * 256 * 8 * 4 * sizeof(unsigned long long));
+    std::vector<unsigned long long> h(5 * 256 * 8 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 2048;
     printf("%-28s", "cycles per wave-instruction");
     const int wps[] = { 1, 2, 4, 5, 8 };
     for (int w : wps) printf("  %d w/SIMD", w);
     printf("   (median wave: s_memtime ticks x waves per SIMD / instructions; 5 -> 5 blocks of 256 threads per CU)\n");
+    // keep the device busy for a while first: the clock it holds under load is part of the answer
+    for (int r = 0; r < 200; r++) hipLaunchKernelGGL(tab[M_FMA3], dim3(2048), dim3(256), 0, 0, d, c, 1.0001f, 2048);
+    hipDeviceSynchronize();
+    std::vector<double> wall_cost(M_COUNT * 5), tick_cost(M_COUNT * 5), clk_ghz(M_COUNT * 5), overlap(M_COUNT * 5);
+    std::vector<int> simds(M_COUNT * 5), wmin(M_COUNT * 5), wmax(M_COUNT * 5);
     for (int m = 0; m < M_COUNT; m++) {
         printf("%-28s", kNames[m]);
-        for (int w : wps) {
+        for (int wi = 0; wi < 5; wi++) {
+            const int w = wps[wi];
             const int grid = 256 * w;
+            const size_t nw = (size_t)grid * 4;
             hipLaunchKernelGGL(tab[m], dim3(grid), dim3(256), 0, 0, d, c, 1.0001f, 16);
+            hipEventRecord(e0, 0);
             hipLaunchKernelGGL(tab[m], dim3(grid), dim3(256), 0, 0, d, c, 1.0001f, iters);
+            hipEventRecord(e1, 0);
             hipDeviceSynchronize();
-            hipMemcpy(h.data(), c, sizeof(unsigned long long) * grid * 4, hipMemcpyDeviceToHost);
-            std::sort(h.begin(), h.begin() + grid * 4);
-            const double ticks = (double)h[grid * 2];
+            float ms = 0.0f; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h.data(), c, sizeof(unsigned long long) * nw * 5, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> t(h.begin(), h.begin() + nw), rt(h.begin() + nw, h.begin() + 2 * nw);
+            std::sort(t.begin(), t.end()); std::sort(rt.begin(), rt.end());
+            const double ticks = (double)t[nw / 2], rticks = (double)rt[nw / 2];
+            // census: waves per (xcc, se, sh, cu, simd)
+            std::vector<unsigned long long> key(h.begin() + 2 * nw, h.begin() + 3 * nw);
+            std::sort(key.begin(), key.end());
+            int n_simd = 0, lo = 1 << 30, hi = 0;
+            for (size_t i = 0; i < nw;) { size_t j = i; while (j < nw && key[j] == key[i]) j++; n_simd++; lo = std::min(lo, (int)(j - i)); hi = std::max(hi, (int)(j - i)); i = j; }
+            // were the waves resident together?  latest start vs earliest end, as a share of the median lifetime
+            const unsigned long long last_start = *std::max_element(h.begin() + 3 * nw, h.begin() + 4 * nw), first_end = *std::min_element(h.begin() + 4 * nw, h.begin() + 5 * nw);
+            const int q = m * 5 + wi;
+            const double ghz = ticks / (rticks * 10.0);                      // s_memrealtime: 100 MHz = 10 ns per tick
+            clk_ghz[q] = ghz; simds[q] = n_simd; wmin[q] = lo; wmax[q] = hi;
+            overlap[q] = ((double)first_end - (double)last_start) / ticks;
             // one wave's lifetime covers the instructions of all w waves sharing its SIMD
-            printf("  %8.2f", ticks / ((double)iters * 64.0 * w));
+            tick_cost[q] = ticks / ((double)iters * 64.0 * w);
+            // wall time: all waves' instructions / SIMDs that held waves, in cycles of the measured clock
+            wall_cost[q] = (double)ms * 1e6 * ghz / ((double)iters * 64.0 * (double)nw / (double)n_simd);
+            printf("  %8.2f", tick_cost[q]);
         }
         printf("\n");
     }
+    printf("\n# the same from the kernel's WALL time (HIP events) x the clock of that launch (s_memtime / s_memrealtime x 100 MHz), per SIMD that held waves\n");
+    printf("%-28s", "cycles per wave-instruction");
+    for (int w : wps) printf("  %d w/SIMD", w);
+    printf("   | clock GHz, SIMDs with waves, waves per SIMD min..max, co-residence (1 = all waves alive together) at 8 w/SIMD\n");
+    for (int m = 0; m < M_COUNT; m++) {
+        printf("%-28s", kNames[m]);
+        for (int wi = 0; wi < 5; wi++) printf("  %8.2f", wall_cost[m * 5 + wi]);
+        const int q = m * 5 + 4;
+        printf("   | %.3f  %d  %d..%d  %.2f\n", clk_ghz[q], simds[q], wmin[q], wmax[q], overlap[q]);
+    }
+    printf("\n# census per column of the first row (v_mul_f32): SIMDs with waves, waves per SIMD min..max, clock GHz, co-residence\n");
+    for (int wi = 0; wi < 5; wi++) printf("#   %d w/SIMD asked: %d SIMDs, %d..%d waves each, %.3f GHz, co-residence %.2f\n", wps[wi], simds[wi], wmin[wi], wmax[wi], clk_ghz[wi], overlap[wi]);
     return 0;
 }

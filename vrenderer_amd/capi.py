@@ -131,7 +131,7 @@ if os.environ.get("VRTERRAIN_LIB"):          # development: A/B another build of
 # every symbol include/vrterrain.h declares
 EXPORTS = [
     "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_set_option", "vr_context_synchronize",
-    "vr_last_error", "vr_version", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
+    "vr_last_error", "vr_version", "vr_build_experiments", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_prepare", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
@@ -175,6 +175,7 @@ def load_library():
         "vr_context_synchronize": (C.c_int, [vp]),
         "vr_last_error": (C.c_char_p, []),
         "vr_version": (C.c_char_p, []),
+        "vr_build_experiments": (C.c_uint32, []),
         "vr_timing_enable": (C.c_int, [vp, C.c_int]),
         "vr_timing_collect": (C.c_int, [vp, P(C.c_float), P(C.c_int32)]),
         "vr_kernel_name": (C.c_char_p, [C.c_int]),

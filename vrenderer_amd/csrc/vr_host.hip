@@ -1,5 +1,6 @@
 // Host side of libvrterrain.so: context, render targets, view helper, partition tables.
 #include "vr_internal.h"
+#include "vr_experiments.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -17,6 +18,7 @@ void vr_set_error(const char* fmt, ...)
 }
 extern "C" VR_API const char* vr_last_error(void) { return g_last_error; }
 extern "C" VR_API const char* vr_version(void) { return "vrterrain 0.1 (gfx950)"; }
+extern "C" VR_API uint32_t vr_build_experiments(void) { return kExpMask; }
 
 // ---- sRGB tables (SRGBA8 fetch / render-target conversion) -------------------------
 static double srgb_eotf(double c) { return c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4); }

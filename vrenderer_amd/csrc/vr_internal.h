@@ -246,6 +246,8 @@ struct GeoSet {
     hipEvent_t ev_sel_read = nullptr;    // recorded behind a lock_view copy OUT of this set (on the copying set's stream)
     bool sel_read_pending = false;
     bool main_waited = false;            // the context's stream already waits for this set's chain (queued by vr_terrain_prepare)
+    hipStream_t main_wait_stream = nullptr;   // ... the stream that wait was queued on: a host may change the context's stream (vr_context_set_stream)
+                                         // between vr_terrain_prepare and vr_terrain_render; the wait only counts for the stream that holds it
     // The geometry stream this set's last chain ran on (the terrain's two streams take turns, so that two prepared
     // frames have their latency-bound chains in flight at once).
     hipStream_t stream = nullptr;

@@ -26,6 +26,7 @@
 // bit-identical to the CPU oracle.
 #include "vr_internal.h"
 #include "vr_tex_dev.h"
+#include "vr_experiments.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -736,29 +737,16 @@ __device__ __forceinline__ void sample_level(const DevTex& hm, const DevTex& al,
     const Axis xa = tap_axis(w, ua), xb = tap_axis(w, ub), x0 = tap_axis(w, u0), y0 = tap_axis(h, v0), ya = tap_axis(h, va), yb = tap_axis(h, vb);
     const int r0 = __mul24(y0.i + 1, w + 2) + 1, ra = __mul24(ya.i + 1, w + 2) + 1, rb = __mul24(yb.i + 1, w + 2) + 1;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifdef VR_EXP_SAMEADDR   // timing experiment only (wrong image): every lane fetches texel 0 - what does the memory system cost?
-    const uint32_t amask = hm.w0 > 100000 ? ~0u : 0u;
-#define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, ((q + (uint32_t)(i)) << 4) & amask, 0, 0)
-#else
 #define LDQ(i) __builtin_amdgcn_raw_buffer_load_b128(rq, (q + (uint32_t)(i)) << 4, 0, 0)
-#endif
     const u32x4 e0 = LDQ(r0 + xa.i), e1 = LDQ(r0 + xb.i), e2 = LDQ(ra + x0.i), e3 = LDQ(rb + x0.i);
     const uint32_t c4 = c << 2;                                   // the decoded chain: 16 B per texel, levels at 4 x the byte offset
-#ifdef VR_EXP_SAMEADDR
-#define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, (((uint32_t)(i) << 4) + c4) & amask, 0, 0)
-#else
 #define LDC(i) __builtin_amdgcn_raw_buffer_load_b128(rc, ((uint32_t)(i) << 4) + c4, 0, 0)
-#endif
     u32x4 p00, p10, p01, p11;
     float cfx, cfy;
     if (SAME) {
         const int cx0 = vr_clampi(x0.i, 0, w - 1), cx1 = vr_clampi(x0.i + 1, 0, w - 1), cy0 = vr_clampi(y0.i, 0, h - 1), cy1 = vr_clampi(y0.i + 1, 0, h - 1);
         const int q0 = __mul24(cy0, w), q1 = __mul24(cy1, w);
-#ifdef VR_EXP_ALB1       // timing experiment only (wrong colours): one albedo fetch instead of four - how much of the pass is the L1?
-        p00 = LDC(q0 + cx0); p10 = p00; p01 = p00; p11 = p00; p11.x += (uint32_t)(q1 + cx1);
-#else
         p00 = LDC(q0 + cx0); p10 = LDC(q0 + cx1); p01 = LDC(q1 + cx0); p11 = LDC(q1 + cx1);
-#endif
         cfx = x0.f; cfy = y0.f;
     } else {
         const BilinearSetup s = vr_bilinear_setup(max(1, al.w0 >> lvl_c), max(1, al.h0 >> lvl_c), u, v);
@@ -811,11 +799,7 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     sample_level<SAME>(hm, al, rq, rc, qoff, aoff, lh.l0, lc.l0, ua, ub, va, vb, u0, v0, u, v, hgt, col);
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
-#ifdef VR_EXP_NOLEVEL1
-    if (hm.w0 > 100000) {
-#else
     if (__any(lh.f > 0.0f || lc.f > 0.0f)) {
-#endif
         // blending with a zero fraction returns the finer sample exactly, so one branch serves both textures
         const int l1h = min(lh.l0 + 1, hm.levels - 1), l1c = min(lc.l0 + 1, al.levels - 1);
         // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
@@ -835,17 +819,13 @@ __device__ __forceinline__ void pixel_shader(const RasterArgs& a, const DevTex& 
     // normalize(): 1.0f / sqrtf(fma(nz, nz, fma(nx, nx, ny * ny))), length in [0.2, 1.43]
     const float inv = vr_rcp_exact(vr_sqrt_exact(__builtin_fmaf(nz, nz, __builtin_fmaf(nx, nx, ny * ny))));
     nx *= inv; ny *= inv; nz *= inv;
-#ifdef VR_EXP_NOENCODE
-    diffuse = (__float_as_uint(col[0]) >> 20) | ((__float_as_uint(col[1]) >> 20) << 8) | ((__float_as_uint(col[2]) >> 20) << 16) | 0xff000000u;
-#else
     diffuse = vr_srgb_encode_fast(col[0], thr, enc) | (vr_srgb_encode_fast(col[1], thr, enc) << 8) | (vr_srgb_encode_fast(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
-#endif
     n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
     n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
 }
 
-// Phase clocks for experiments (tools/build_variant.py prof -DVR_RASTER_PROFILE); not in the product build.
+// Phase clocks for experiments (tools/build_variant.py prof -DVR_RASTER_PROFILE; needs -DVR_EXPERIMENT_BUILD, vr_experiments.h); not in the product build.
 #ifdef VR_RASTER_PROFILE
 constexpr int kProfBlocks = 16384;
 constexpr int kProfSlots = 16;
@@ -913,24 +893,16 @@ __device__ __forceinline__ FastTaps issue_level_fast(__amdgpu_buffer_rsrc_t rq, 
     FAST_AXIS(t.fxa, xa, ua, wf, 16.0f); FAST_AXIS(t.fxb, xb, ub, wf, 16.0f); FAST_AXIS(t.fx0, x0, u0, wf, 16.0f);
     FAST_AXIS(t.fy0, y0, v0, hf, 1.0f); FAST_AXIS(t.fya, ya, va, hf, 1.0f); FAST_AXIS(t.fyb, yb, vb, hf, 1.0f);
     const uint32_t row0 = L.x + (uint32_t)__mul24(y0, (int)L.y), rowa = L.x + (uint32_t)__mul24(ya, (int)L.y), rowb = L.x + (uint32_t)__mul24(yb, (int)L.y);
-#define LD(r_, o_) __builtin_amdgcn_raw_buffer_load_b128((r_), (o_), 0, 0)
-#ifdef VR_EXP_FAST_SAMEADDR   // timing experiments only (wrong image): every fetch at the table's first entries / fewer fetches per level
-    t.e0 = LD(rq, (row0 + (uint32_t)xa) & 0xf0u); t.e1 = LD(rq, (row0 + (uint32_t)xb) & 0xf0u); t.e2 = LD(rq, (rowa + (uint32_t)x0) & 0xf0u); t.e3 = LD(rq, (rowb + (uint32_t)x0) & 0xf0u);
-    const uint32_t a00 = (row0 + (uint32_t)x0) & 0xf0u, a01 = a00 + 256u;
-    t.p00 = LD(rc, a00); t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u);
-#elif defined(VR_EXP_FAST_ALB1)
-    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0);
-    const uint32_t a00 = row0 + (uint32_t)x0;
-    t.p00 = LD(rc, a00); t.p10 = t.p00; t.p01 = t.p00; t.p11 = t.p00;
-#elif defined(VR_EXP_FAST_HGT1)
-    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = t.e0; t.e2 = t.e0; t.e3 = t.e0; (void)rowa; (void)rowb; (void)xb;
-    const uint32_t a00 = row0 + (uint32_t)x0;
-    t.p00 = LD(rc, a00); t.p10 = t.p00; t.p01 = t.p00; t.p11 = t.p00;
-#else
-    t.e0 = LD(rq, row0 + (uint32_t)xa); t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0);
+    // (kExp*: timing experiments, all false in a product build - vr_experiments.h)
+    const uint32_t am = kExpSameAddr ? 0xf0u : ~0u;
+#define LD(r_, o_) __builtin_amdgcn_raw_buffer_load_b128((r_), (o_) & am, 0, 0)
     const uint32_t a00 = row0 + (uint32_t)x0, a01 = a00 + L.y;
-    t.p00 = LD(rc, a00); t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u);
-#endif
+    t.e0 = LD(rq, row0 + (uint32_t)xa);
+    if (!kExpOneHeight) { t.e1 = LD(rq, row0 + (uint32_t)xb); t.e2 = LD(rq, rowa + (uint32_t)x0); t.e3 = LD(rq, rowb + (uint32_t)x0); }
+    t.p00 = LD(rc, a00);
+    if (!(kExpOneHeight || kExpOneAlbedo)) { t.p10 = LD(rc, a00 + 16u); t.p01 = LD(rc, a01); t.p11 = LD(rc, a01 + 16u); }
+    if (kExpOneHeight) { t.e1 = t.e0; t.e2 = t.e0; t.e3 = t.e0; }
+    if (kExpOneHeight || kExpOneAlbedo) { t.p10 = t.p00; t.p01 = t.p00; t.p11 = t.p00; }
 #undef LD
     return t;
 }
@@ -973,11 +945,7 @@ __device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f
     }
     // Wave-uniform branch (ballot): where every pixel of the wave is magnified (LOD 0 - the near half of an 8K frame)
     // the whole second level is skipped; a per-lane condition gets if-converted and every pixel pays for both levels.
-#ifdef VR_EXP_FAST_NOLEVEL1  // timing experiment only (wrong image): no coarser level
-    if (a.w < 0) {
-#else
-    if (__any(frac > 0.0f)) {
-#endif
+    if (kExpNoLevel1 ? a.w < 0 : __any(frac > 0.0f)) {
         const int l16b = (int)(fminf(lf + 1.0f, max_level) * 16.0f);
         // The coordinates pass through an empty asm so that nothing of this level can be hoisted above the branch
         float xa = ua, xb = ub, ya = va, yb = vb, x0 = u, y0 = v;
@@ -996,6 +964,8 @@ __device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f
     float nx = -hDx, ny = 2.0f * offset, nz = -hDy;                                          // :63
     const float inv = vr_rcp_exact(vr_sqrt_exact(__builtin_fmaf(nz, nz, __builtin_fmaf(nx, nx, ny * ny))));
     nx *= inv; ny *= inv; nz *= inv;
+    if (kExpNoEncode) diffuse = (__float_as_uint(col[0]) >> 20) | ((__float_as_uint(col[1]) >> 20) << 8) | ((__float_as_uint(col[2]) >> 20) << 16) | 0xff000000u;
+    else
     diffuse = srgb_encode_nonneg(col[0], thr, enc) | (srgb_encode_nonneg(col[1], thr, enc) << 8) | (srgb_encode_nonneg(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
     n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
@@ -1181,23 +1151,11 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
 {
     static_assert(!RANGES || MODE == RM_FAST, "depth ranges come with the fast variant");
     __shared__ unsigned long long vis[TILE * TILE];
-#ifdef VR_EXP_GLOBAL_TABLES   // experiment: the small tables read from global memory, so that a 64-pixel tile's workgroup needs exactly 32 KB of LDS (5 per CU)
-    const uint8_t* __restrict__ enc = enc_g;
-    const float* __restrict__ thr = thr_g;
-    const uint32_t* __restrict__ s_qoff = hm.qoff;
-    const uint32_t* __restrict__ s_aoff = al.off;
-#else
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float thr[kThrTabSize];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
-#endif
     __shared__ uint4 s_lv[kMaxLevels];                 // fast variant: DevTex::fast_lv (the same for both textures)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef VR_LDS_PAD      // experiments only: extra LDS per workgroup = fewer workgroups per CU (occupancy sensitivity of the tile pass)
-    __shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
-    if (a.w < 0) lds_pad[tid] = (uint32_t)tid;
-    if (a.h < 0) g_diff[0] = lds_pad[tid ^ 1];
-#endif
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
@@ -1208,7 +1166,6 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     // a fifth of a 32-pixel tile's time (4K: init + record fetch = 21 % of the wave cycles).
     uint4 lv_r = make_uint4(0, 0, 0, 0);
     if (MODE == RM_FAST && tid < kMaxLevels) lv_r = hm.fast_lv[tid];
-#ifndef VR_EXP_GLOBAL_TABLES
     uint32_t qoff_r = 0, aoff_r = 0;
     if (MODE != RM_FAST && tid < kMaxLevels) { qoff_r = hm.qoff[tid]; aoff_r = al.off[tid]; }
     constexpr int kEncWords = (kEncTabSize + 3) / 4, kEncPer = (kEncWords + kRT - 1) / kRT;
@@ -1216,7 +1173,6 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
 #pragma unroll
     for (int q = 0; q < kEncPer; q++) enc_r[q] = tid + q * kRT < kEncWords ? reinterpret_cast<const uint32_t*>(enc_g)[tid + q * kRT] : 0u;
     const float thr_r = tid < 256 ? thr_g[tid] : 0.0f;
-#endif
     const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
     // consecutive bin entries go to different waves so that a short list still uses all of them
     const uint32_t idx0 = (uint32_t)(lane * kRW + wave);
@@ -1241,13 +1197,11 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         vis[i] = key;
     }
     if (MODE == RM_FAST && tid < kMaxLevels) s_lv[tid] = lv_r;
-#ifndef VR_EXP_GLOBAL_TABLES
     if (MODE != RM_FAST && tid < kMaxLevels) { s_qoff[tid] = qoff_r; s_aoff[tid] = aoff_r; }
 #pragma unroll
     for (int q = 0; q < kEncPer; q++) if (tid + q * kRT < kEncWords) reinterpret_cast<uint32_t*>(enc)[tid + q * kRT] = enc_r[q];
     if (tid < 256) thr[tid] = thr_r;
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
-#endif
     __syncthreads();
     VR_PROF_MARK(0);
 
@@ -1467,6 +1421,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         }
         const uint32_t off = idx << 7;                           // an uncovered pixel: 0x0fffffff << 7 = far beyond rec_bytes -> zeros
         Rec r;
+        if (kExpNoRecord) { r.g5 = (u32x4){ 0x3f800000u, 0u, 0u, 0u }; r.g6 = (u3){ off, 0x3a800000u, 0u }; r.g7 = (u3){ 0x3f000000u, 0u, 0x3a800000u }; return r; }
         r.g5 = __builtin_amdgcn_raw_buffer_load_b128(rrec, off, 80, 0);
         r.g6 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 96, 0);
         r.g7 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 112, 0);
@@ -1499,13 +1454,9 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         }
         const bool inside = whole || (gy0 < a.h && gx < a.w);     // (per lane) this column lies on the target
         uint32_t pix = (uint32_t)__umul24(gy0, a.w) + (uint32_t)gx;          // < 2^28: both factors below 2^14
-#ifdef VR_EXP_TILED_STORES   // timing experiment only (scrambled image): every tile's pixels contiguous in each plane
-        uint32_t pix4 = ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2;
-        const uint32_t w4 = (uint32_t)TILE << 2;
-#else
-        uint32_t pix4 = pix << 2;                                            // byte offset in a 4-byte plane (a row further: + 4 w)
-        const uint32_t w4 = (uint32_t)a.w << 2;
-#endif
+        // byte offset in a 4-byte plane (a row further: + 4 w)
+        uint32_t pix4 = kExpTiledStores ? ((uint32_t)tile * (uint32_t)(TILE * TILE) + (uint32_t)(ly0 * TILE + lx)) << 2 : pix << 2;
+        const uint32_t w4 = kExpTiledStores ? (uint32_t)TILE << 2 : (uint32_t)a.w << 2;
 #pragma unroll
         for (int k = 0; k < 4; k++, pix += (uint32_t)a.w, pix4 += w4) {
             const unsigned long long key = keys[k];
@@ -1547,10 +1498,10 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                 if (FAST) pixel_shader_fast(a, w0f, h0f, max_level, rq, rc, thr, enc, s_lv, p, dif, nn0, nn1 VR_PROF_ARG);
                 else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
-#ifdef VR_EXP_NOSTORE     // timing experiment only: nothing leaves (a dependent dummy keeps the shading alive)
-            if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
-            continue;
-#endif
+            if (kExpNoStore) {        // (a dependent dummy keeps the shading alive)
+                if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
+                continue;
+            }
             if (gb_small) {
                 __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
                 if (!depth_only) {
@@ -1559,7 +1510,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                     __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
                     __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
-                    __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
+                    if (!kExpNoEmissive) __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
                 }
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
@@ -1769,7 +1720,7 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     bool other_prepared = false;
     for (const GeoSet& p : t->sets) other_prepared |= (&p != &g) && p.prepared;
     if (other_prepared) g.main_waited = false;
-    else { VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0)); g.main_waited = true; }
+    else { VR_HIP(hipStreamWaitEvent(t->ctx->stream, g.ev_geo_done, 0)); g.main_waited = true; g.main_wait_stream = t->ctx->stream; }
     g.prepared = true; g.prep_view = *view; g.prep_rp = *rp; g.prep_w = gb->w; g.prep_h = gb->h; g.prep_rank = a.rank; g.prep_world = a.world; g.prep_tile_shift = a.tile_shift;
     g.prep_serial = ++t->prep_counter;
     return VR_OK;
@@ -1804,7 +1755,8 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         if ((rc = launch_geometry(t, g, sel, view, rp, a, pt))) return rc;
     }
     t->cur = gi;
-    if (!(use_prepared && g.main_waited)) VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));     // the tile pass consumes verts + bins
+    // the tile pass consumes verts + bins (a wait queued at prepare time counts only if it sits on the stream this pass runs on)
+    if (!(use_prepared && g.main_waited && g.main_wait_stream == s)) VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));
     g.main_waited = false;
     const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
     const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
@@ -1848,7 +1800,7 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
     g.raster_recorded = true;
     // chains prepared further ahead whose wait vr_terrain_prepare left for later: behind this tile pass
     for (GeoSet& p : t->sets)
-        if (&p != &g && p.prepared && !p.main_waited && p.geo_recorded) { VR_HIP(hipStreamWaitEvent(s, p.ev_geo_done, 0)); p.main_waited = true; }
+        if (&p != &g && p.prepared && !(p.main_waited && p.main_wait_stream == s) && p.geo_recorded) { VR_HIP(hipStreamWaitEvent(s, p.ev_geo_done, 0)); p.main_waited = true; p.main_wait_stream = s; }
     VR_HIP(hipGetLastError());
     return VR_OK;
 }

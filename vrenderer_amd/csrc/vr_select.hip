@@ -12,6 +12,7 @@
 // Nothing is allocated per frame and nothing crosses PCIe: UpdateTransforms
 // (TerrainPass.cpp:234-256) is fused into the write-out.
 #include "vr_internal.h"
+#include "vr_experiments.h"
 
 #include <math.h>
 #include <string.h>
