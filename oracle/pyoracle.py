@@ -79,6 +79,9 @@ def lib():
     L.orc_deferred.argtypes = [P(View), C.c_int, C.c_int, vp, vp, vp, vp, vp, P(Light), C.c_int,
                                P(C.c_float), P(C.c_float), vp]
     L.orc_deferred_f32.argtypes = L.orc_deferred.argtypes
+    L.orc_debug_set_pixel_plane.argtypes = [vp]
+    L.orc_debug_set_pixel_plane.restype = None
+    L.orc_model_revision.restype = C.c_int
     L.orc_synth_heightmap.argtypes = [C.c_int, C.c_uint32, vp]
     L.orc_synth_albedo.argtypes = [C.c_int, C.c_uint32, vp, vp]
     L.orc_half_to_float.restype = C.c_float
@@ -231,10 +234,24 @@ class OracleTerrain:
         lib().orc_vertex(self.handle, C.byref(view), max_height, C.byref(inst), vx, vz, clip, world)
         return np.array(clip[:], np.float32), np.array(world[:], np.float32)
 
-    def render(self, view, gb, rp, part=None):
-        return lib().orc_render(self.handle, C.byref(view), C.byref(rp), C.byref(part) if part is not None else None,
-                                gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular),
-                                _ptr(gb.normals), _ptr(gb.emissive))
+    def render(self, view, gb, rp, part=None, debug_plane=None):
+        """debug_plane: optional (h, w, 3) float32 array that receives, per shaded pixel, main_ps's implicit LOD (before the
+        sampler's clamp) and the interpolated world x, z (orc_debug_set_pixel_plane; not part of the model)."""
+        if debug_plane is not None:
+            assert debug_plane.dtype == np.float32 and debug_plane.shape == (gb.h, gb.w, 3) and debug_plane.flags.c_contiguous
+            lib().orc_debug_set_pixel_plane(_ptr(debug_plane))
+        try:
+            return lib().orc_render(self.handle, C.byref(view), C.byref(rp), C.byref(part) if part is not None else None,
+                                    gb.w, gb.h, _ptr(gb.depth), _ptr(gb.diffuse), _ptr(gb.specular),
+                                    _ptr(gb.normals), _ptr(gb.emissive))
+        finally:
+            if debug_plane is not None:
+                lib().orc_debug_set_pixel_plane(None)
+
+
+def model_revision():
+    """Revision of the oracle's raster / sampler model (frozen from round 4 on; tests/golden/MODEL_REVISIONS.txt)."""
+    return lib().orc_model_revision()
 
 
 def shadow_view(light, camera_view, params):

@@ -31,6 +31,12 @@
 #define _POSIX_C_SOURCE 200809L
 #include "vr_oracle.h"
 
+/* The raster / sampler model's revision (header comment above).  FROZEN from round 4 on: tests/test_oracle_cpu.py bounds this
+ * revision against an exact (float64 / rational) evaluation of the HLSL semantics and pins its output by digest
+ * (tests/golden/MODEL_REVISIONS.txt); a change of any per-pixel result needs a new revision number, a new digest line and
+ * the diff statistics against that float64 model in the commit.  A kernel optimisation is no reason for one. */
+#define ORC_MODEL_REVISION 3
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -840,16 +846,23 @@ static orc_attr interp(const orc_planes* P, float dx, float dy)
     return a;
 }
 
+/* Debug tap for tests/test_oracle_cpu.py (no part of the model): when set, every shaded pixel also leaves the implicit
+ * level of detail main_ps's Sample calls used (before the sampler's clamp) and its interpolated world xz. */
+static float* g_dbg_plane = NULL;       /* w * h * 3 floats: lod, world x, world z */
+void orc_debug_set_pixel_plane(float* plane) { g_dbg_plane = plane; }
+int  orc_model_revision(void) { return ORC_MODEL_REVISION; }
+
 /* main_ps (terrain_ps.hlsl:45-82) for one pixel; p = world xz at the pixel centre with its
  * screen-space derivatives (for the implicit LOD of Sample). */
 static void pixel_shader(const orc_terrain* t, orc_attr p,
-                         uint32_t* diffuse, uint32_t* specular, uint16_t normals[4], uint16_t emissive[4])
+                         uint32_t* diffuse, uint32_t* specular, uint16_t normals[4], uint16_t emissive[4], float* dbg)
 {
     float halfSize = t->p.world_size * 0.5f, ws = t->p.world_size;
     float u = (p.wx + halfSize) / ws, v = (p.wz + halfSize) / ws;                      /* :12-13,20-21 */
     float dudx = p.dwxdx / ws, dvdx = p.dwzdx / ws, dudy = p.dwxdy / ws, dvdy = p.dwzdy / ws;
     float lod_h = lod_from_derivs(dudx, dvdx, dudy, dvdy, t->height.w[0], t->height.h[0]);
     float lod_c = lod_from_derivs(dudx, dvdx, dudy, dvdy, t->albedo.w[0], t->albedo.h[0]);
+    if (dbg) { dbg[0] = lod_h; dbg[1] = p.wx; dbg[2] = p.wz; }
     const float offset = 0.1f;                                                         /* :59 */
     float a[3], b[3];
     tex_trilinear(&t->height, lod_h, u + offset, v + 0.0f, a);
@@ -898,7 +911,8 @@ static void fragment(const orc_frag_ctx* f, int x, int y)
     tg->depth[idx] = z + 0.0f;
     if (tg->depth_only) return;
     orc_attr p = interp(&f->P, dx, dy);
-    pixel_shader(f->t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4]);
+    pixel_shader(f->t, p, &tg->diffuse[idx], &tg->specular[idx], &tg->normals[idx*4], &tg->emissive[idx*4],
+                 g_dbg_plane ? g_dbg_plane + idx * 3 : NULL);
 }
 
 static inline int64_t floor_div(int64_t num, int64_t den)

@@ -109,6 +109,12 @@ float  orc_exp2_pinned(float x);
 void   orc_synth_heightmap(int size, uint32_t seed, uint8_t* out_r8);
 void   orc_synth_albedo(int size, uint32_t seed, const uint8_t* height_r8, uint8_t* out_srgba8);
 
+/* Revision of the raster / sampler model (vr_oracle.c header), frozen from round 4 on; and a debug tap for the test that
+ * bounds the model against a float64 evaluation: plane = w*h*3 floats (implicit LOD before the sampler's clamp, world x,
+ * world z of every shaded pixel of the following orc_render calls), NULL = off.  Not part of the model. */
+int    orc_model_revision(void);
+void   orc_debug_set_pixel_plane(float* plane);
+
 /* small helpers exposed for tests */
 float    orc_half_to_float(uint16_t h);
 uint16_t orc_float_to_half(float f);

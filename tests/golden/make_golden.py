@@ -46,9 +46,27 @@ def main():
             rp = vr.default_render_params(400.0)
             t.render(v, gb, rp)
             hdr = po.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)
+            # The oracle's raster / sampler model is frozen per revision: one digest line per revision, never rewritten.
+            import hashlib
+            m = hashlib.sha256()
+            for arr in (gb.depth, gb.diffuse, gb.specular, gb.normals, gb.emissive, hdr):
+                m.update(np.ascontiguousarray(arr).tobytes())
+            rev, digest = po.model_revision(), m.hexdigest()
+            rev_file = os.path.join(OUT, "MODEL_REVISIONS.txt")
+            known = {}
+            if os.path.exists(rev_file):
+                known = {int(l.split()[0]): l.split()[1] for l in open(rev_file) if l.strip() and not l.startswith("#")}
+            if rev in known and known[rev] != digest:
+                raise SystemExit(f"the oracle's output changed but ORC_MODEL_REVISION is still {rev}: bump it (oracle/vr_oracle.c), "
+                                 "state the diff statistics against tests/f64_model.py in the commit, then run this again")
+            if rev not in known:
+                with open(rev_file, "a") as f:
+                    if not known:
+                        f.write("# model revision -> sha256 of the golden 256x144 frame's planes (depth, diffuse, specular, normals, emissive, hdr)\n")
+                    f.write(f"{rev} {digest}\n")
             np.savez_compressed(os.path.join(OUT, "frame_256x144.npz"), depth=gb.depth, diffuse=gb.diffuse,
                                 specular=gb.specular, normals=gb.normals, emissive=gb.emissive, hdr=hdr,
-                                view=np.frombuffer(bytes(v), np.uint8))
+                                view=np.frombuffer(bytes(v), np.uint8), model_revision=np.int32(rev))
         t.close()
     np.savez_compressed(os.path.join(OUT, "select_ids.npz"), **sel)
     print("wrote", os.listdir(OUT))

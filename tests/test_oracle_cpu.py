@@ -2,8 +2,11 @@
 
 The reference has no tests or fixtures; what pins the oracle is (i) the node counts the
 survey measured on the reference's own QuadTree.cpp, (ii) closed-form
-known answers, (iii) an independent float64 numpy restatement of the shading model.
+known answers, (iii) an independent float64 numpy restatement of the shading model, (iv) an exact-arithmetic
+(float64 / rational) evaluation of the draw written from the HLSL / D3D semantics (tests/f64_model.py), against
+which the oracle's raster / sampler model is BOUNDED - and, from round 4 on, FROZEN (model revision + digest).
 """
+import hashlib
 import os
 
 import numpy as np
@@ -116,6 +119,81 @@ def test_golden_frame_regression(oracle, t256):
         assert np.array_equal(getattr(gb, name), g[name]), name
     hdr = oracle.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)
     assert np.array_equal(hdr, g["hdr"])
+
+
+def _frame_digest(gb, hdr):
+    m = hashlib.sha256()
+    for a in (gb.depth, gb.diffuse, gb.specular, gb.normals, gb.emissive, hdr):
+        m.update(np.ascontiguousarray(a).tobytes())
+    return m.hexdigest()
+
+
+def test_model_revision_is_frozen(oracle, t256):
+    """From round 4 on the oracle's per-pixel results may only change together with its model revision: the golden frame
+    carries the revision it was made with, and tests/golden/MODEL_REVISIONS.txt holds one digest per revision - a changed
+    output under an old number fails here, and make_golden.py refuses to overwrite a revision's digest."""
+    g = np.load(os.path.join(GOLD, "frame_256x144.npz"))
+    rev = oracle.model_revision()
+    assert int(g["model_revision"]) == rev, "tests/golden/frame_256x144.npz was made by another model revision"
+    lines = [l.split() for l in open(os.path.join(GOLD, "MODEL_REVISIONS.txt")) if l.strip() and not l.startswith("#")]
+    digests = {int(a): b for a, b in lines}
+    assert rev in digests, f"revision {rev} has no digest line in tests/golden/MODEL_REVISIONS.txt"
+    w, h = 256, 144
+    v = oracle.view_from_camera(*scaled_camera(CAMERAS[0], 256), w, h)
+    gb = oracle.GBufferHost(w, h)
+    t256.render(v, gb, vr.default_render_params(400.0))
+    hdr = oracle.deferred(v, gb, [vr.reference_sun()], AMBIENT_TOP, AMBIENT_BOTTOM)
+    assert _frame_digest(gb, hdr) == digests[rev], ("the oracle's output changed without a new model revision "
+                                                    "(oracle/vr_oracle.c: ORC_MODEL_REVISION; DESIGN.md 2)")
+
+
+@pytest.mark.parametrize("cam", [0, 1, 5, 6])
+def test_raster_and_sampler_model_is_bounded_by_exact_arithmetic(oracle, t256, cam):
+    """The oracle's implementation choices (raster model revision 3: per-triangle plane equations set up in double and
+    evaluated with two fmaf per pixel, fused sampler arithmetic, a pinned cubic for log2) against tests/f64_model.py - the
+    same draw evaluated from the HLSL / D3D text with exact integer edge functions, rational barycentrics and float64
+    everywhere.  Bounds (the golden 256x144 frame's camera and three more):
+      coverage          identical, and no pixel whose depth test was decided by less than 4 fp32 ulps
+      depth             within 1 fp32 ulp of the correctly rounded exact value (<= 1.5 ulp absolute)
+      world xz          within 4 fp32 ulps (of the world's half size: 6e-5 units, 6e-5 texels) of the exact perspective-correct interpolation
+      implicit LOD      within 2e-3 of log2(rho) (the pinned cubic's 1.1e-3 + fp32 rounding)
+      albedo (SRGBA8)   at most one code, on at most 0.1 % of the covered pixels (sampled at the oracle's LOD)
+      normal (SNORM16)  at most one code per component, on at most 2 % of the components
+    The HIP path is then bit-exact against the oracle (tests/test_gpu_parity.py), so these bounds carry over to it."""
+    from tests import f64_model as F
+    w, h, size = 256, 144, 256
+    v = oracle.view_from_camera(*scaled_camera(CAMERAS[cam], size), w, h)
+    gb = oracle.GBufferHost(w, h)
+    dbg = np.zeros((h, w, 3), np.float32)
+    t256.render(v, gb, vr.default_render_params(400.0), debug_plane=dbg)
+    hml = [t256.height_mip(l) for l in range(t256.height_levels())]
+    alb = [t256.albedo_mip(l) for l in range(t256.albedo_levels())]
+    fr = F.render(t256, v, w, h, 400.0, float(size), hml, alb, lod_for_sampling=dbg[..., 0])
+    cov = gb.depth < 1.0
+    assert cov.sum() > 4000 and fr.tri_count["rasterised"] > 2000
+    assert np.array_equal(cov, fr.covered), f"coverage differs at {(cov != fr.covered).sum()} pixels"
+    assert fr.ambiguous.sum() == 0 and fr.from_clipper.sum() == 0
+    m = cov
+    exact32 = fr.depth.astype(np.float32)
+    ulps = np.abs(gb.depth.view(np.int32).astype(np.int64) - exact32.view(np.int32).astype(np.int64))
+    assert ulps[m].max() <= 1, f"depth: {ulps[m].max()} ulps from the rounded exact value"
+    err = np.abs(gb.depth.astype(np.float64) - fr.depth) / np.spacing(exact32).astype(np.float64)
+    assert err[m].max() <= 1.5
+    for k, exact in ((1, fr.wx), (2, fr.wz)):
+        e = np.abs(dbg[..., k].astype(np.float64) - exact) / float(np.spacing(np.float32(size / 2)))
+        assert e[m].max() <= 4.0, f"world {'xz'[k - 1]}: {e[m].max():.2f} ulps of the world's half size"
+    assert fr.lod[m].min() < 0.0 and fr.lod[m].max() > 2.0, "the frame must hold magnified and minified pixels"
+    dl = np.abs(dbg[..., 0].astype(np.float64) - fr.lod)
+    assert dl[m].max() <= 2e-3, f"implicit LOD: {dl[m].max():.5f}"
+    rgb = np.stack([(gb.diffuse >> (8 * k)) & 255 for k in range(3)], -1).astype(np.int64)
+    dc = np.abs(rgb - fr.albedo_codes)[m]
+    assert dc.max() <= 1 and (dc.max(-1) > 0).mean() <= 1e-3, (dc.max(), (dc.max(-1) > 0).mean())
+    nn = gb.normals[..., :3].view(np.int16).astype(np.int64)
+    dn = np.abs(nn - fr.normal_codes)[m]
+    assert dn.max() <= 1 and (dn > 0).mean() <= 0.02, (dn.max(), (dn > 0).mean())
+    assert np.all(gb.normals[..., 3][m] == 32767) and np.all(gb.emissive[m] == 0)
+    spec = int(oracle.lib().orc_linear_to_srgb8(np.float32(0.01)))                    # terrain_ps.hlsl:76
+    assert np.all(gb.specular[m] == (spec | spec << 8 | spec << 16 | 0xff000000))
 
 
 def test_flat_terrain_known_answers(oracle):
