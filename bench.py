@@ -145,8 +145,10 @@ def main():
                     help="pin the tile pass's raster tile edge (VR_OPT_RASTER_TILE); 0 = by frame size and split (default)")
     ap.add_argument("--no-depth-ranges", action="store_true",
                     help="--lights N: the tiled pass's culling stage reads the depth plane instead of the ranges the tile pass leaves")
-    ap.add_argument("--prewarm-laps", type=int, default=1,
-                    help="untimed laps of the 120-frame camera path rendered during set-up, before the warm-up steps (device clock ramp)")
+    ap.add_argument("--prewarm-laps", type=int, default=0,
+                    help="untimed laps of the 120-frame camera path rendered during set-up, before the warm-up steps (device clock ramp); "
+                         "0 (default): --warmup means exactly what it says and the figure after a lap of load is reported beside it ('sustained')")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the second timed region (the same K frames after one more lap of load)")
     ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
                     help="vr_timing_enable level inside the timed region: 2 = dispatch-stamped events on the two big kernels (default), "
                          "1 = event records around every kernel, 0 = none (no per-kernel figures; measures what the stamps cost)")
@@ -195,6 +197,7 @@ def main():
     import numpy as np
     torch = None
     dist = None
+    comm = None            # this rank's ncclComm_t for the C-ABI exchange (vrenderer_amd.rccl.Communicator)
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -216,13 +219,24 @@ def main():
                 warm = torch.zeros(1, device="cuda")
                 dist.all_reduce(warm)
                 torch.cuda.synchronize()
+                # The exchange of the timed loop goes through the library's own entry points (vr_tonemap_allreduce_histogram,
+                # vr_frame_allgather[_tiles/_ldr]: include/vrterrain.h), which take the host's ncclComm_t: one communicator of
+                # this job's ranks, made from the RCCL already in the process; rank 0's unique id travels over the process group.
+                from vrenderer_amd import rccl
+                uid = torch.zeros(rccl.NCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(rccl.get_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                comm = rccl.Communicator(world, rank, uid.cpu().numpy().tobytes())
+                torch.cuda.synchronize()
             finally:
                 sys.stdout.flush()
                 os.dup2(saved_stdout, 1)
                 os.close(saved_stdout)
 
     import vrenderer_amd as vr
-    from vrenderer_amd.passes import frame_detile, frame_detile_ldr, partition_info, partition_prepare
+    from vrenderer_amd.passes import (frame_allgather, frame_allgather_ldr, frame_allgather_tiles, frame_detile, frame_detile_ldr, partition_info,
+                                      partition_prepare)
     from vrenderer_amd.scene import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
 
     W, H, size = args.width, args.height, args.size
@@ -313,6 +327,7 @@ def main():
         if ctx_post is not ctx_comm:
             partition_prepare(ctx_post, W, H, part)
         ldr = args.exchange == "ldr"
+        one_call = nbuf == 1 and comm is not None       # everything on one stream: vr_frame_allgather[_ldr] (gather + de-tile)
         if ldr:
             # f3: the frame leaves each rank tone-mapped (Renderer.cpp:430-431); all of it runs on the exchange stream
             tmp = vr.default_tonemap_params()
@@ -352,22 +367,25 @@ def main():
     views = [vr.make_view(*camera(i), W, H) for i in range(120)]
 
     def allgather(dst_u8, src_u8):
-        if args.rehearse_on_one_gpu:
+        """This rank's packed tiles -> every rank's `gathered` buffer, on the exchange stream: ncclAllGather through the C ABI
+        (vr_frame_allgather_tiles; RCCL over xGMI, equal send counts)."""
+        if args.rehearse_on_one_gpu:                                       # (debug: gloo on host copies stands in for RCCL)
             comm_stream.synchronize()
             host = torch.empty(dst_u8.numel(), dtype=torch.uint8)
             dist.all_gather_into_tensor(host, src_u8.cpu())
             dst_u8.copy_(host)
         else:
-            dist.all_gather_into_tensor(dst_u8, src_u8)                    # RCCL over xGMI, equal send counts
+            frame_allgather_tiles(ctx_comm, comm, src_u8.data_ptr(), dst_u8.data_ptr(), world, src_u8.numel())
 
     def allreduce(t_i32):
+        """The tone mapper's 256 histogram bins summed over the ranks: vr_tonemap_allreduce_histogram (ncclAllReduce)."""
         if args.rehearse_on_one_gpu:
             comm_stream.synchronize()
             host = t_i32.cpu()
             dist.all_reduce(host)
             t_i32.copy_(host)
         else:
-            dist.all_reduce(t_i32)
+            tm.AllReduceHistogram(comm)
 
     def light(v, out_img, p):
         if tiled:
@@ -430,20 +448,27 @@ def main():
                 tm.ComputeExposure(tmp)
                 tm.Render(tmp, hdr_bufs[b], ldr_bufs[b], W, H, part)       # packed RGB16F tiles -> packed RGB8 tiles
                 if ev: ev[2].record(comm_stream)
-                allgather(gathered_ldr[b], packed_ldr[b])
+                if one_call:         # --no-overlap: all-gather + de-tile as ONE call of the C ABI, on the one stream
+                    frame_allgather_ldr(ctx_comm, comm, packed_ldr[b].data_ptr(), gathered_ldr[b].data_ptr(), world, W, H, frame)
+                else:
+                    allgather(gathered_ldr[b], packed_ldr[b])
                 if ev: ev[3].record(comm_stream)
             else:
                 if ev: ev[0].record(comm_stream); ev[1].record(comm_stream); ev[2].record(comm_stream)
-                allgather(gathered[b].view(torch.uint8), packed[b][:half_elems].view(torch.uint8))
+                if one_call:
+                    frame_allgather(ctx_comm, comm, packed[b].data_ptr(), gathered[b].data_ptr(), world, frame)
+                else:
+                    allgather(gathered[b].view(torch.uint8), packed[b][:half_elems].view(torch.uint8))
                 if ev: ev[3].record(comm_stream)
             gather_done[b].record(comm_stream)
             comm_done[b].record(comm_stream)
         with torch.cuda.stream(post_stream):
             post_stream.wait_event(gather_done[b])
-            if ldr:
-                frame_detile_ldr(ctx_post, gathered_ldr[b].data_ptr(), world, W, H, frame)
-            else:
-                frame_detile(ctx_post, gathered[b].data_ptr(), world, frame)
+            if not one_call:         # the de-tile of frame i on its own stream, under the all-gather of frame i+1
+                if ldr:
+                    frame_detile_ldr(ctx_post, gathered_ldr[b].data_ptr(), world, W, H, frame)
+                else:
+                    frame_detile(ctx_post, gathered[b].data_ptr(), world, frame)
             post_done[b].record(post_stream)
 
     def sync():
@@ -456,11 +481,12 @@ def main():
         else:
             ctx.synchronize()
 
-    # Set-up, before the W warm-up steps the contract names: the camera path once, untimed.  The device idles through the
-    # seconds of host-side set-up above (context, textures, tables) and needs ~15 ms of load to return to its sustained
-    # clocks; the W = 5 warm-up frames of the driver's command are 3 ms.  Measured on one box, the same 20 frames:
-    # 0.584-0.590 ms per frame straight after 5 warm-up frames, 0.547-0.550 ms after a lap (profiles/r03_clock_ramp.txt).
-    # Disclosed in the line ("untimed_setup"); --prewarm-laps 0 gives the raw figure.
+    # The contract: W untimed warm-up steps, then exactly K timed steps - `value`.  The device idles through the seconds of
+    # host-side set-up above (context, textures, tables) and needs ~15 ms of load to return to its sustained clocks; the W = 5
+    # warm-up frames of the driver's command are 3 ms, so `value` contains that ramp (same 20 frames: 0.584-0.590 ms straight
+    # after 5 warm-up frames, 0.547-0.550 ms after a lap; profiles/r03_clock_ramp.txt).  Round 3 rendered an untimed lap here
+    # by default; now --prewarm-laps defaults to 0 and the figure after a lap of load is measured in a SECOND timed region
+    # behind the first and reported beside it ("sustained").
     import gc
     gc.collect(); gc.disable()               # no collector pause while the host queues the warm-up and timed frames (20 frames are 11 ms);
                                              # here, not between warm-up and timed region: a collection there idles the device for tens of
@@ -498,6 +524,26 @@ def main():
     for c in side_ctxs:
         timings.update(c.timing_collect())
         c.timing_enable(False)
+    # the same K frames once more after a further lap of load (clocks ramped): reported beside `value`, never instead of it
+    sustained = None
+    if args.prewarm_laps == 0 and not args.no_sustained:
+        gc.collect(); gc.disable()
+        for i in range(120):
+            step(args.warmup + args.steps + i)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + args.steps + 120 + i)
+        gc.enable()
+        sync()
+        el2 = time.perf_counter() - t1
+        if use_dist:
+            t2 = torch.tensor([el2], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            el2 = float(t2.item())
+        sustained = {"value": round(W * H * args.steps / el2 / 1e9, 3), "unit": "Gpixels/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                     "what": f"the same {args.steps} steps timed again behind one further lap (120 frames) of load, when the device has returned to its "
+                             "sustained clocks after the idle set-up phase (round 3's `value` was measured like this: its bench rendered an untimed lap first)"}
     kernels_note = None
     if timing_level == 2:
         # the small kernels (geometry chain, tone-map stage, de-tile), timed with events around every launch over a few
@@ -543,9 +589,9 @@ def main():
         idx = args.warmup + args.steps - 1
         if use_dist and ldr:
             tm.ResetExposure(0.0)       # the adapted luminance has a history; restart it for the comparison frame
-            idx += 1
-            step(idx)
-            sync()
+        idx += 1                        # (other frames may have been rendered since the timed region: render the comparison frame now)
+        step(idx)
+        sync()
         last = views[idx % 120]
         got = frame.download()
         ref_img = vr.HdrImage(ctx, W, H)
@@ -665,7 +711,15 @@ def main():
             ach = DEFERRED_BYTES_PER_PX * owned_px / pair_s / 1e9
             roof_deferred.update({"kernel": "k_light_cull + k_deferred_tiled", "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                                   "avg_us": round(pair_s * 1e6, 2)})
-        roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px)
+        # bytes the tile pass really writes per pixel: 28, or 20 while the library knows the emissive plane is all zero and does not
+        # rewrite it (VR_OPT_PLANE_TRACKING: main_ps's o_channel3 = 0 lands on zeros)
+        emissive_skipped = bool(rt.plane_known_zero("emissive"))
+        raster_bytes = GBUFFER_BYTES_PER_PX - (8 if emissive_skipped else 0)
+        roof_raster = roof("k_raster", raster_bytes, owned_px)
+        if roof_raster:
+            roof_raster["bytes_per_pixel"] = raster_bytes
+            roof_raster["emissive_plane"] = ("known zero (cleared at creation, only zeros written since): not rewritten, 20 of the G-buffer's 28 B/px leave the pass"
+                                             if emissive_skipped else "written")
         if roof_raster:
             # the tile pass only writes: what a store-only kernel of its own pattern reaches on this part (tools/micro/fill_rate.hip:
             # 929 MB in 156-163 us), next to the 8 TB/s of reads and writes together that `peak` is
@@ -678,6 +732,7 @@ def main():
             "untimed_setup": (f"{args.prewarm_laps} lap(s) of the 120-frame camera path rendered before the {args.warmup} warm-up steps: the device "
                               "needs ~15 ms of load after the host-side set-up to reach its sustained clocks (same 20 frames: 0.585 ms straight "
                               "after 5 warm-up frames, 0.549 ms after a lap; --prewarm-laps 0 for the raw figure)") if args.prewarm_laps else None,
+            "sustained": sustained,
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    + (f"1 sun + {args.lights - 1} point lights (seed 9001, range 20-80) through the tiled pass; " if tiled
                                       else "1 directional light; ")
@@ -725,7 +780,11 @@ def main():
                                "rank_compute_us": round(compute_us, 1), "frame_period_us": round(period_us, 1),
                                "overlap": round(hidden / exchange_us, 3) if exchange_us > 0 else None,
                                "bytes_received_per_rank": int((world - 1) * (info["packed_bytes_ldr"] if ldr else info["packed_bytes"])),
-                               "what": "HIP events on rank 0's exchange stream around dist.all_reduce (256 histogram bins) and dist.all_gather_into_tensor "
+                               "through": ("gloo on host copies (rehearsal)" if comm is None else
+                                           "the C ABI: vr_tonemap_allreduce_histogram + " + ("vr_frame_allgather_ldr / vr_frame_allgather (gather + de-tile in one call)" if one_call
+                                                                                             else "vr_frame_allgather_tiles, vr_frame_detile[_ldr] on a third stream")
+                                           + ", ncclComm_t of this job's ranks (vrenderer_amd/rccl.py)"),
+                               "what": "HIP events on rank 0's exchange stream around the all-reduce (256 histogram bins) and the all-gather "
                                        "(packed tiles) of every timed frame, including the wait for the slowest peer; rank_compute_us = tile pass + "
                                        "lighting of rank 0's tiles; overlap = share of the exchange hidden behind the next frame's rendering"}
         if verified is not None:
@@ -783,6 +842,8 @@ def main():
 
     if use_dist:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

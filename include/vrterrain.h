@@ -98,8 +98,9 @@ typedef struct vr_render_params {
     int32_t depth_ranges; /* extension: 1 = leave the depth range of every 32x32 light tile with the G-buffer
                              (needs assume_cleared, shaded fill mode); vr_deferred_light_tiled's culling
                              stage then takes them instead of reading the depth plane again.  Any other
-                             write to the G-buffer in between (clear, upload, another render, describe)
-                             drops them; results are identical either way                      */
+                             write to the G-buffer in between (clear, upload, another render) drops them,
+                             and a G-buffer whose pointers were handed out (vr_gbuffer_describe) never
+                             gets them; results are identical either way                      */
     int32_t reserved[2];
 } vr_render_params;
 
@@ -158,7 +159,13 @@ VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submi
  * cross-stream dependencies - no event-record packets sit between the two kernels.  0 = explicit hipEventRecord. */
 /* VR_OPT_RASTER_TILE (default 0): edge of the tile pass's raster tiles - 0 = chosen by frame size and split (32 pixels below
  * ~13000 64-pixel tiles per rank, i.e. up to about 9.6K x 5.4K; 64 above), 32 or 64 = pinned.  The rendered frame does not depend on it. */
-enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE = 3 };
+/* VR_OPT_PLANE_TRACKING (default 1): main_ps writes 0 to the emissive target for every pixel (terrain_ps.hlsl:80) and Clear writes 0
+ * everywhere, so on this path the emissive plane - 8 of the G-buffer's 28 B/pixel - only ever holds zeros.  While the library knows
+ * the plane is all zero (it cleared it - vr_gbuffer_create / vr_gbuffer_clear - or a tile pass that writes every pixel ran since the
+ * last foreign write) the tile pass does not rewrite it; the plane's contents are the same either way.  vr_gbuffer_upload of the
+ * plane ends that knowledge until the next clear or whole-target pass; vr_gbuffer_describe ends it for good (the pointers have left
+ * the library), and likewise the depth ranges of vr_render_params::depth_ranges.  0 = every pass writes all five planes. */
+enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE = 3, VR_OPT_PLANE_TRACKING = 4 };
 VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);
@@ -255,7 +262,12 @@ VR_API int  vr_terrain_num_chunks(vr_terrain* t, uint32_t* count);
 VR_API int  vr_gbuffer_create(vr_context* ctx, int32_t width, int32_t height, vr_gbuffer** out);
 VR_API void vr_gbuffer_destroy(vr_gbuffer* gb);
 VR_API int  vr_gbuffer_clear(vr_gbuffer* gb);
+/* The device pointers of the planes, for interop.  From this call on the library assumes nothing about the planes' contents
+ * (a host may write through the pointers at any time): vr_render_params::depth_ranges is ignored and every tile pass writes
+ * all five planes (VR_OPT_PLANE_TRACKING) for the rest of this G-buffer's life. */
 VR_API int  vr_gbuffer_describe(vr_gbuffer* gb, vr_gbuffer_desc* out);
+/* 1 when the library knows `plane` (4 = emissive; others: 0) holds only zeros and the next tile pass will not rewrite it. */
+VR_API int  vr_gbuffer_plane_known_zero(vr_gbuffer* gb, int plane);
 /* test/IO helpers: copy planes host<->device (synchronous). plane: 0 depth,
  * 1 diffuse, 2 specular, 3 normals, 4 emissive. */
 VR_API int  vr_gbuffer_download(vr_gbuffer* gb, int plane, void* host, size_t bytes);
@@ -367,6 +379,12 @@ VR_API int    vr_frame_detile(vr_context* ctx, const void* gathered_device, int3
  * one that made the communicator), else from librccl.so; libvrterrain.so itself does not link it. */
 VR_API int    vr_frame_allgather(vr_context* ctx, void* nccl_comm, const void* packed_device, void* gathered_device,
                                  int32_t world_size, vr_image* frame_out);
+
+/* The all-gather alone, for a host that de-tiles on another stream (vr_frame_detile[_ldr] on a second context, so that the
+ * de-tile of frame i runs under the all-gather of frame i+1): ncclAllGather of bytes_per_rank bytes (vr_partition_packed_bytes
+ * or vr_partition_packed_bytes_ldr) from packed_device into gathered_device (world_size x that) on the context's stream. */
+VR_API int    vr_frame_allgather_tiles(vr_context* ctx, void* nccl_comm, const void* packed_device, void* gathered_device,
+                                       int32_t world_size, size_t bytes_per_rank);
 
 /* ---- tone mapping to LdrColor ------------------------------- */
 /* donut::render::ToneMappingPass as used by the reference: created with default CreateParameters

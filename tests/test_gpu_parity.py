@@ -1088,6 +1088,72 @@ def test_context_stream_changed_between_prepare_and_render(scene2048, oracle, gp
         rt.close()
 
 
+def test_emissive_plane_tracking_never_changes_the_gbuffer(scene256, oracle, gpu_ctx):
+    """VR_OPT_PLANE_TRACKING: main_ps writes 0 to the emissive target (terrain_ps.hlsl:80) and Clear writes 0, so the tile pass
+    skips the plane while the library knows it is all zero.  Whatever the history - fresh target, foreign writes (upload),
+    partitioned and keep-what-is-there passes, pointers handed out - the five planes equal the oracle's, and the library's
+    knowledge follows the rules of include/vrterrain.h."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 512, 288
+    v = vr.make_view(*scaled_camera(CAMERAS[0], 256), w, h)
+    rp_c, rp_k = vr.default_render_params(400.0, assume_cleared=1), vr.default_render_params(400.0)
+    want = oracle.GBufferHost(w, h)
+    ot.render(v, want, rp_k)                                   # Clear + Render
+    rng = np.random.default_rng(11)
+    junk = rng.integers(1, 65535, (h, w, 4), dtype=np.uint16)
+    names = ("depth", "diffuse", "specular", "normals", "emissive")
+
+    def planes(rt):
+        return {k: rt.download(k) for k in names}
+    for tracking in (True, False):
+        gpu_ctx.set_plane_tracking(tracking)
+        try:
+            rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+            assert rt.plane_known_zero() == tracking           # created cleared
+            tp.Render(v, v, rt, rp_c)
+            _assert_gbuffer_equal(want, planes(rt), f"fresh target (tracking {tracking})")
+            assert rt.plane_known_zero() == tracking
+            # a foreign write: the knowledge is gone; a partitioned pass over a 'cleared' target zeroes its own tiles only
+            rt.upload("emissive", junk)
+            assert not rt.plane_known_zero()
+            part = vr.Partition(1, 3)
+            tp.Render(v, v, rt, rp_c, part)
+            got = planes(rt)
+            ty, tx = np.indices((h, w))
+            owned = ((tx // 128 + ty // 128) % 3) == 1
+            assert np.array_equal(got["emissive"][owned], want.emissive[owned]) and np.array_equal(got["emissive"][~owned], junk[~owned])
+            for k in ("diffuse", "specular", "normals"):
+                assert np.array_equal(got[k][owned], getattr(want, k)[owned]), k
+            assert not rt.plane_known_zero()
+            # a whole-target pass over a 'cleared' target writes every pixel's emissive texel: known zero again
+            tp.Render(v, v, rt, rp_c)
+            _assert_gbuffer_equal(want, planes(rt), f"whole-target pass after a foreign write (tracking {tracking})")
+            assert rt.plane_known_zero() == tracking
+            tp.Render(v, v, rt, rp_c)                          # ... and this one skips the plane
+            _assert_gbuffer_equal(want, planes(rt), f"second pass (tracking {tracking})")
+            # keep-what-is-there pass on junk: zeros where the terrain is drawn, junk elsewhere; not known zero
+            rt.Clear(); rt.upload("emissive", junk)
+            tp.Render(v, v, rt, rp_k)
+            got = planes(rt)
+            cov = want.depth < 1.0
+            assert np.array_equal(got["emissive"][cov], want.emissive[cov]) and np.array_equal(got["emissive"][~cov], junk[~cov])
+            assert not rt.plane_known_zero()
+            # ... on a cleared target it stays known
+            rt.Clear(); assert rt.plane_known_zero() == tracking
+            tp.Render(v, v, rt, rp_k)
+            _assert_gbuffer_equal(want, planes(rt), f"Clear + Render (tracking {tracking})")
+            assert rt.plane_known_zero() == tracking
+            # pointers handed out: never known again, not even after a clear
+            rt.describe(); assert not rt.plane_known_zero()
+            rt.Clear(); assert not rt.plane_known_zero()
+            rt.upload("emissive", junk)
+            tp.Render(v, v, rt, rp_c)
+            _assert_gbuffer_equal(want, planes(rt), f"after describe (tracking {tracking})")
+            rt.close()
+        finally:
+            gpu_ctx.set_plane_tracking(True)
+
+
 def test_deferred_spot_and_spherical_lights(scene256, oracle, gpu_ctx):
     """All three Donut light types through the streaming pass (ShadeSurface: cone falloff by
     1 - smoothstep(inner, outer, angle), spherical sources with a per-pixel half angle)."""
@@ -1137,6 +1203,39 @@ def test_two_rank_frame_split_rehearsal_on_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["frame_verified_against_unsplit"] is True
+
+
+@pytest.mark.parametrize("mode", ["ldr", "hdr", "ldr-one-stream"])
+def test_bench_n_rank_path_through_rccl_and_the_c_abi(mode):
+    """bench.py's REAL N > 1 code path on this one GPU (--force-dist: a one-rank process group on the nccl backend): its own
+    ncclComm_t (vrenderer_amd/rccl.py), packed tiles, the histogram all-reduce and the all-gather through the exported
+    exchange (vr_tonemap_allreduce_histogram, vr_frame_allgather_tiles + vr_frame_detile[_ldr], or - on one stream -
+    vr_frame_allgather[_ldr]), de-tile; the assembled frame equals the unsplit render and the line carries the `exchange`
+    record.  What the first 8-GPU run executes, minus the peers."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--width", "1920", "--height", "1080",
+           "--verify", "--no-cpu-baseline", "--exchange", mode.split("-")[0]] + (["--no-overlap"] if mode.endswith("one-stream") else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout (RCCL's banner must not land there)"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["frame_verified_against_unsplit"] is True
+    x = out["exchange"]
+    assert "C ABI" in x["through"] and ("vr_frame_allgather_ldr" in x["through"] if mode.endswith("one-stream") else "vr_frame_allgather_tiles" in x["through"])
+    assert x["allgather_us"] > 0 and x["frame_period_us"] > 0 and x["bytes_received_per_rank"] == 0
+    assert (x["allreduce_us"] > 0) == (mode != "hdr")
+    assert "k_raster" in out["kernels"] and ("k_detile_ldr" if mode != "hdr" else "k_detile") in out["kernels"]
+    assert out["sustained"]["value"] > 0
 
 
 def _render_view_both(sc, oracle, gpu_ctx, v, w, h, **rpkw):

@@ -25,6 +25,7 @@ VR_TONEMAP_BINS = 256
 VR_OPT_ASYNC_GEOMETRY = 1
 VR_OPT_DISPATCH_EVENTS = 2
 VR_OPT_RASTER_TILE = 3
+VR_OPT_PLANE_TRACKING = 4
 
 
 class TerrainParams(C.Structure):
@@ -134,14 +135,14 @@ EXPORTS = [
     "vr_last_error", "vr_version", "vr_build_experiments", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_prepare", "vr_terrain_num_chunks",
-    "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe",
+    "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe", "vr_gbuffer_plane_known_zero",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_ldr_image_create", "vr_ldr_image_destroy", "vr_ldr_image_device_ptr", "vr_ldr_image_capacity", "vr_ldr_image_download", "vr_ldr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_deferred_tiled_status", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile",
     "vr_shadow_default_params", "vr_shadow_view_setup", "vr_deferred_light_shadowed",
     "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
     "vr_tonemap_add_frame_to_histogram", "vr_tonemap_histogram_device_ptr", "vr_tonemap_compute_exposure", "vr_tonemap_render",
-    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_allgather", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_tile_order", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
+    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_allgather", "vr_frame_allgather_tiles", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_tile_order", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
 ]
 
 _lib = None
@@ -200,6 +201,7 @@ def load_library():
         "vr_gbuffer_destroy": (None, [vp]),
         "vr_gbuffer_clear": (C.c_int, [vp]),
         "vr_gbuffer_describe": (C.c_int, [vp, P(GBufferDesc)]),
+        "vr_gbuffer_plane_known_zero": (C.c_int, [vp, C.c_int]),
         "vr_gbuffer_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "vr_gbuffer_upload": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "vr_image_create": (C.c_int, [vp, C.c_int32, C.c_int32, vp, P(vp)]),
@@ -225,6 +227,7 @@ def load_library():
         "vr_frame_detile": (C.c_int, [vp, vp, C.c_int32, vp]),
         "vr_frame_allgather": (C.c_int, [vp, vp, vp, vp, C.c_int32, vp]),
         "vr_frame_allgather_ldr": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+        "vr_frame_allgather_tiles": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_size_t]),
         "vr_tonemap_allreduce_histogram": (C.c_int, [vp, vp]),
         "vr_shadow_default_params": (None, [P(ShadowParams), C.c_float]),
         "vr_shadow_view_setup": (C.c_int, [P(Light), P(View), P(ShadowParams), P(View)]),

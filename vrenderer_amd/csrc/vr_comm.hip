@@ -79,6 +79,14 @@ extern "C" VR_API int vr_frame_allgather(vr_context* ctx, void* nccl_comm, const
     return vr_frame_detile(ctx, gathered, world, frame_out);
 }
 
+extern "C" VR_API int vr_frame_allgather_tiles(vr_context* ctx, void* nccl_comm, const void* packed, void* gathered, int32_t world, size_t bytes_per_rank)
+{
+    VR_REQUIRE(ctx && nccl_comm && packed && gathered && world >= 1 && bytes_per_rank > 0, "bad arguments");
+    int rc = rccl_load(); if (rc) return rc;
+    VR_HIP(hipSetDevice(ctx->device));
+    return rccl_check(g_rccl.all_gather(packed, gathered, bytes_per_rank, kNcclUint8, nccl_comm, ctx->stream), "ncclAllGather");
+}
+
 extern "C" VR_API int vr_frame_allgather_ldr(vr_context* ctx, void* nccl_comm, const void* packed_ldr, void* gathered, int32_t world,
                                               int32_t w, int32_t h, void* ldr_frame)
 {

@@ -99,8 +99,9 @@ extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
 extern "C" VR_API int vr_context_set_option(vr_context* c, int option, int value)
 {
     VR_REQUIRE(c != nullptr, "ctx is NULL");
-    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS || option == VR_OPT_RASTER_TILE, "unknown option");
+    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS || option == VR_OPT_RASTER_TILE || option == VR_OPT_PLANE_TRACKING, "unknown option");
     if (option == VR_OPT_ASYNC_GEOMETRY) c->async_geometry = value != 0;
+    else if (option == VR_OPT_PLANE_TRACKING) c->plane_tracking = value != 0;
     else if (option == VR_OPT_RASTER_TILE) {
         VR_REQUIRE(value == 0 || value == 32 || value == 64, "VR_OPT_RASTER_TILE: 0 (by size), 32 or 64");
         c->raster_tile_force = value == 32 ? 5 : value == 64 ? 6 : 0;
@@ -453,7 +454,14 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
     if ((rc = fill_u32(s, g->specular, n, 0u))) return rc;
     if ((rc = fill_u32(s, g->normals, n * 2, 0u))) return rc;
     if ((rc = fill_u32(s, g->emissive, n * 2, 0u))) return rc;
+    g->emissive_zero = true;               // (stream-ordered: every later pass on the context's stream sees the zeros)
     return VR_OK;
+}
+
+extern "C" VR_API int vr_gbuffer_plane_known_zero(vr_gbuffer* g, int plane)
+{
+    if (!g || plane != 4) return 0;
+    return (g->ctx->plane_tracking && g->emissive_zero && !g->escaped) ? 1 : 0;
 }
 
 __global__ void k_fill_u32x2(uint2* p, size_t n, uint32_t x, uint32_t y)
@@ -480,7 +488,9 @@ int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s)
 extern "C" VR_API int vr_gbuffer_describe(vr_gbuffer* g, vr_gbuffer_desc* d)
 {
     VR_REQUIRE(g && d, "NULL argument");
-    vr_gbuffer_touch(g);           // the caller gets the device pointers: whatever it writes through them is unknown here
+    vr_gbuffer_touch(g);           // the caller gets the device pointers: whatever it writes through them is unknown here,
+    g->escaped = true;             // now and for as long as the G-buffer lives (no depth ranges, no plane-state tracking any more)
+    g->emissive_zero = false;
     d->width = g->w; d->height = g->h; d->depth = g->depth; d->diffuse = g->diffuse; d->specular = g->specular;
     d->normals = g->normals; d->emissive = g->emissive;
     return VR_OK;
@@ -516,6 +526,7 @@ extern "C" VR_API int vr_gbuffer_upload(vr_gbuffer* g, int plane, const void* ho
     VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
     VR_HIP(hipSetDevice(g->ctx->device));
     vr_gbuffer_touch(g);
+    if (plane == 4) g->emissive_zero = false;
     VR_HIP(hipMemcpyAsync(p, host, nb, hipMemcpyHostToDevice, g->ctx->stream));
     VR_HIP(hipStreamSynchronize(g->ctx->stream));
     return VR_OK;

@@ -136,6 +136,7 @@ struct vr_context {
     // shadow map's and the main view's geometry every frame)
     std::vector<PartTables*> part_tables;
     bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
+    bool plane_tracking = true;    // VR_OPT_PLANE_TRACKING: the tile pass does not rewrite a G-buffer plane the library knows to be all zero (vr_gbuffer)
     int raster_tile_force = 0;     // VR_OPT_RASTER_TILE: 0 = by size (vr_raster_tile_shift), 5 / 6 = 32- / 64-pixel raster tiles
     // VR_OPT_DISPATCH_EVENTS: the tile pass and the lighting pass are launched with hipExtLaunchKernelGGL, whose start/stop
     // events are stamped by the dispatch itself; the stop events double as the cross-stream dependencies (tile pass done ->
@@ -193,6 +194,15 @@ struct vr_gbuffer {
     enum { RANGES_NONE = 0, RANGES_CLEAN, RANGES_VALID, RANGES_DIRTY };
     int ranges_state = RANGES_NONE;          // CLEAN: every entry "none"; VALID: the last writer of the G-buffer left them; DIRTY: stale
     int ranges_rank = 0, ranges_world = 1;   // the screen-tile split they were rendered for
+    // Plane-state tracking (VR_OPT_PLANE_TRACKING): main_ps writes 0 to the emissive target for every pixel it shades
+    // (terrain_ps.hlsl:80) and RenderTargets::Clear writes 0 everywhere, so on this path the plane only ever holds zeros -
+    // 8 of the G-buffer's 28 bytes per pixel.  While the library KNOWS the plane is all zero (it cleared it, or a tile pass
+    // that writes every pixel of the target has run since the last foreign write) the tile pass does not rewrite it.
+    // Foreign writes: vr_gbuffer_upload of the plane -> not known zero; vr_gbuffer_describe -> the pointers have left the
+    // library for good (`escaped`): nothing about the planes' contents is assumed ever again (the same goes for the light
+    // tiles' depth ranges above).
+    bool emissive_zero = false;
+    bool escaped = false;
 };
 // (anything else that writes the G-buffer: its depth ranges are stale)
 inline void vr_gbuffer_touch(vr_gbuffer* g) { if (g->ranges_state == vr_gbuffer::RANGES_VALID) g->ranges_state = vr_gbuffer::RANGES_DIRTY; }

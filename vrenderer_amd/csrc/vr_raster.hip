@@ -1131,7 +1131,9 @@ constexpr int kRT = VR_RASTER_THREADS, kRW = kRT / 64;
 //   RM_GENERIC everything else, decided at run time.
 enum { RM_GENERIC = 0, RM_FAST = 1, RM_DEPTH = 2 };
 // RANGES (fast variant only): the depth range of every 32x32 light tile is left at `ranges` for the tiled lighting pass.
-template <bool WIRE, int TILE, int MODE, bool RANGES = false>
+// NOEMI (fast variant only): the emissive plane is known to hold zeros already (vr_gbuffer::emissive_zero) and is not rewritten -
+// main_ps's o_channel3 = 0 (terrain_ps.hlsl:80) changes nothing there; 8 of the 28 bytes a pixel sends through the CU's store path.
+template <bool WIRE, int TILE, int MODE, bool RANGES = false, bool NOEMI = false>
 // A 32-pixel tile's workgroup needs 11 KB of LDS: registers, not LDS, decide how many fit a CU.  Asked for six waves per SIMD
 // the compiler fits every 32-pixel variant into 80 VGPRs without a spill (84-90 otherwise: five waves): 5120x2880 frame
 // 0.288 -> 0.279 ms, 4K 0.203 -> 0.2015, the rank of an 8-way split 0.128 -> 0.126 (profiles/r03_tile32_waves.txt).
@@ -1149,7 +1151,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                                                  const float* __restrict__ thr_g,
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const, uint2* __restrict__ ranges)
 {
-    static_assert(!RANGES || MODE == RM_FAST, "depth ranges come with the fast variant");
+    static_assert((!RANGES && !NOEMI) || MODE == RM_FAST, "depth ranges and the emissive skip come with the fast variant");
     __shared__ unsigned long long vis[TILE * TILE];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
     __shared__ float thr[kThrTabSize];
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                     __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
                     __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
-                    if (!kExpNoEmissive) __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
+                    if (!NOEMI && !kExpNoEmissive) __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
                 }
             } else {
                 const size_t p64 = (size_t)(gy0 + k) * a.w + gx;
@@ -1669,6 +1671,16 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
     return VR_OK;
 }
 
+typedef decltype(&k_raster<false, 32, RM_GENERIC>) raster_kernel_t;
+template <int TILE>
+static raster_kernel_t pick_raster(bool wire, bool fast, bool depth, bool ranges, bool noemi)
+{
+    if (wire) return k_raster<true, TILE, RM_GENERIC>;
+    if (fast) return ranges ? (noemi ? k_raster<false, TILE, RM_FAST, true, true> : k_raster<false, TILE, RM_FAST, true, false>)
+                            : (noemi ? k_raster<false, TILE, RM_FAST, false, true> : k_raster<false, TILE, RM_FAST, false, false>);
+    return depth ? k_raster<false, TILE, RM_DEPTH> : k_raster<false, TILE, RM_GENERIC>;
+}
+
 static bool prepared_matches(const GeoSet& g, const vr_view* view, const vr_render_params* rp, int w, int h, const RasterArgs& a)
 {
     return memcmp(&g.prep_view, view, sizeof(vr_view)) == 0 && g.prep_rp.max_height == rp->max_height && g.prep_rp.depth_only == rp->depth_only
@@ -1780,20 +1792,22 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         const bool fast = same && a.ws_pow2 && one_rsrc && !a.wireframe && !a.depth_only;
         const bool depth = a.depth_only && !a.wireframe;
         // the light tiles' depth ranges, if asked for: only from the fast variant over a target it fills completely
-        const bool ranges = rp->depth_ranges && fast && a.assume_cleared;
+        const bool ranges = rp->depth_ranges && fast && a.assume_cleared && !gb->escaped;
         if (ranges) {
             if ((rc = vr_gbuffer_ranges_prepare(gb, s))) return rc;
             gb->ranges_state = vr_gbuffer::RANGES_VALID; gb->ranges_rank = a.rank; gb->ranges_world = a.world;
         } else vr_gbuffer_touch(gb);
-        auto kern = a.tile_shift == 5
-            ? (a.wireframe ? k_raster<true, 32, RM_GENERIC> : ranges ? k_raster<false, 32, RM_FAST, true> : fast ? k_raster<false, 32, RM_FAST>
-               : depth ? k_raster<false, 32, RM_DEPTH> : k_raster<false, 32, RM_GENERIC>)
-            : (a.wireframe ? k_raster<true, 64, RM_GENERIC> : ranges ? k_raster<false, 64, RM_FAST, true> : fast ? k_raster<false, 64, RM_FAST>
-               : depth ? k_raster<false, 64, RM_DEPTH> : k_raster<false, 64, RM_GENERIC>);
+        // plane-state tracking: the emissive plane holds zeros already and the fast variant would only write zeros again
+        const bool noemi = fast && ctx->plane_tracking && gb->emissive_zero && !gb->escaped;
+        auto kern = a.tile_shift == 5 ? pick_raster<32>(a.wireframe != 0, fast, depth, ranges, noemi) : pick_raster<64>(a.wireframe != 0, fast, depth, ranges, noemi);
         VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
                            (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0,
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr);
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
+        // a shaded pass over a cleared target writes the emissive texel (0) of EVERY pixel of the frame, covered or not: from here
+        // on the plane is known zero again, whatever it held (a partitioned or keep-what-is-there pass writes zeros to some pixels:
+        // the state stays what it was)
+        if (!noemi && !a.depth_only && a.assume_cleared && a.world <= 1) gb->emissive_zero = true;
     }
     if (pass_stop) { g.raster_done = pass_stop; g.raster_done_epoch = ctx->ev_epoch; }
     else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; g.raster_done_epoch = 0; }

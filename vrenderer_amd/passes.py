@@ -44,6 +44,10 @@ class Context:
         """Edge of the tile pass's raster tiles: 0 = by frame size and split (default), 32 or 64 = pinned."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_RASTER_TILE, int(edge)), "vr_context_set_option")
 
+    def set_plane_tracking(self, enable):
+        """The tile pass does not rewrite a G-buffer plane the library knows to be all zero (the emissive plane; default on)."""
+        check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_PLANE_TRACKING, int(enable)), "vr_context_set_option")
+
     def set_dispatch_events(self, enable):
         """Tile pass / lighting pass launched with dispatch-stamped events that double as cross-stream dependencies (default on)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_DISPATCH_EVENTS, int(enable)), "vr_context_set_option")
@@ -156,6 +160,10 @@ class RenderTargets:
 
     def Clear(self):
         check(self.ctx.lib.vr_gbuffer_clear(self.handle), "vr_gbuffer_clear")
+
+    def plane_known_zero(self, plane="emissive"):
+        """True when the next tile pass will not rewrite `plane` because the library knows it holds only zeros."""
+        return bool(self.ctx.lib.vr_gbuffer_plane_known_zero(self.handle, self.PLANES[plane][0]))
 
     def describe(self):
         d = GBufferDesc()
@@ -294,6 +302,11 @@ class ToneMappingPass:
         """ResetHistogram + AddFrameToHistogram + ComputeExposure + Render (one GPU)."""
         check(self.ctx.lib.vr_tonemap_simple_render(self.handle, C.byref(params), self.frame_time, hdr.handle,
                                                     C.c_void_p(ldr.device_ptr), ldr.capacity), "vr_tonemap_simple_render")
+
+    def AllReduceHistogram(self, comm):
+        """The tone mapper's one exchange step between AddFrameToHistogram(partition) and ComputeExposure: the 256 bins summed
+        over the ranks (ncclAllReduce on this pass's context stream; comm: vrenderer_amd.rccl.Communicator or an ncclComm_t)."""
+        check(self.ctx.lib.vr_tonemap_allreduce_histogram(self.handle, getattr(comm, "handle", comm)), "vr_tonemap_allreduce_histogram")
 
     def download(self):
         hist = np.zeros(capi.VR_TONEMAP_BINS, np.uint32)
@@ -569,6 +582,25 @@ def partition_prepare(ctx, width, height, partition):
 def frame_detile_ldr(ctx, gathered_ptr, world, width, height, ldr):
     check(ctx.lib.vr_frame_detile_ldr(ctx.handle, C.c_void_p(gathered_ptr), world, width, height, C.c_void_p(ldr.device_ptr)),
           "vr_frame_detile_ldr")
+
+
+def frame_allgather_ldr(ctx, comm, packed_ptr, gathered_ptr, world, width, height, ldr):
+    """vr_frame_allgather_ldr: ncclAllGather of this rank's packed RGB8 tiles on the context's stream + the de-tile into the
+    row-major SRGBA8 frame `ldr` (comm: vrenderer_amd.rccl.Communicator or an ncclComm_t)."""
+    check(ctx.lib.vr_frame_allgather_ldr(ctx.handle, getattr(comm, "handle", comm), C.c_void_p(packed_ptr), C.c_void_p(gathered_ptr), world,
+                                         width, height, C.c_void_p(ldr.device_ptr)), "vr_frame_allgather_ldr")
+
+
+def frame_allgather(ctx, comm, packed_ptr, gathered_ptr, world, frame):
+    """vr_frame_allgather: the same for packed RGB16F tiles into the row-major RGBA16F `frame` (an HdrImage)."""
+    check(ctx.lib.vr_frame_allgather(ctx.handle, getattr(comm, "handle", comm), C.c_void_p(packed_ptr), C.c_void_p(gathered_ptr), world,
+                                     frame.handle), "vr_frame_allgather")
+
+
+def frame_allgather_tiles(ctx, comm, packed_ptr, gathered_ptr, world, bytes_per_rank):
+    """vr_frame_allgather_tiles: the all-gather alone; the host de-tiles where it likes (frame_detile[_ldr] on another context)."""
+    check(ctx.lib.vr_frame_allgather_tiles(ctx.handle, getattr(comm, "handle", comm), C.c_void_p(packed_ptr), C.c_void_p(gathered_ptr), world,
+                                           bytes_per_rank), "vr_frame_allgather_tiles")
 
 
 def frame_detile(ctx, gathered_ptr, world, frame):
