@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--prewarm-laps", type=int, default=0,
                     help="untimed laps of the 120-frame camera path rendered during set-up, before the warm-up steps (device clock ramp); "
                          "0 (default): --warmup means exactly what it says and the figure after a lap of load is reported beside it ('sustained')")
+    ap.add_argument("--no-submit", action="store_true",
+                    help="queue a frame through the per-call entry points (Render, Prepare x 2, Light, tone-map stage: ~9 calls) instead of "
+                         "vr_frame_submit (one call); A/B of the host's cost per frame")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second timed region (the same K frames after one more lap of load)")
     ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
                     help="vr_timing_enable level inside the timed region: 2 = dispatch-stamped events on the two big kernels (default), "
@@ -398,11 +401,26 @@ def main():
         if args.prepare_depth > 1:
             tp.Prepare(views[(i + 2) % 120], rt, rp, p)      # ... and frame i+2's: a second chain in flight (a no-op for a frame already prepared)
 
+    # one call per frame (vr_frame_submit: Render [+ Clear] -> Prepare x 2 -> lighting [-> tone-map stage]); the shadow path keeps
+    # the per-call sequence (its shadow-map pass sits between frames)
+    use_submit = not args.no_submit and shadow_map is None and not args.no_prepare
+    frame_call = None
+    if use_submit:
+        stage = dict(tonemap=tm, tonemap_params=tmp, ldr=ldr_img) if (emu and emu_ldr) else {}
+        frame_call = vr.Frame(tp, rt, rp, tiled_lights if tiled else lights, AMBIENT_TOP, AMBIENT_BOTTOM, part, tiled, **stage)
+
+    def submit(i, out_img):
+        ahead = [views[(i + 1) % 120]] + ([views[(i + 2) % 120]] if args.prepare_depth > 1 else [])
+        frame_call.submit(views[i % 120], out_img, ahead)
+
     def step(i):
         v = views[i % 120]
         if shadow_map is not None:                  # every rank renders the whole (small) shadow map
             shadow_map.SetupForPlanarViewStable(lights[0], v)
             shadow_map.RenderTerrain(tp)
+        if use_submit and not use_dist:
+            submit(i, emu_hdr[i % 2] if emu else hdr)        # (an emulated rank rotates two tile buffers; the library orders the two streams)
+            return
         if not use_dist:
             out_img = emu_hdr[i % 2] if emu else hdr
             if emu and emu_ldr:
@@ -427,10 +445,13 @@ def main():
             return
         b = i % nbuf
         main_stream.wait_event(comm_done[b])        # packed[b] / gathered[b] are free again (no-op before first use)
-        tp.Render(v, v, rt, rp, part)
-        if not args.no_prepare and shadow_map is None:
-            prepare_ahead(i, part)
-        light(v, hdr_bufs[b], part)
+        if use_submit:
+            submit(i, hdr_bufs[b])
+        else:
+            tp.Render(v, v, rt, rp, part)
+            if not args.no_prepare and shadow_map is None:
+                prepare_ahead(i, part)
+            light(v, hdr_bufs[b], part)
         render_done[b].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
@@ -754,6 +775,7 @@ def main():
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 4),
             # how long the host needed to queue a frame: if this approaches ms_per_step the loop is host-bound, not device-bound
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
+            "host_calls_per_frame": "1 (vr_frame_submit)" if use_submit and not use_dist else ("vr_frame_submit + the exchange stage's calls" if use_submit else "per-call API"),
         }
         if kernels_note:
             out["kernels_note"] = kernels_note

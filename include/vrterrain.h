@@ -444,6 +444,40 @@ VR_API int  vr_frame_allgather_ldr(vr_context* ctx, void* nccl_comm, const void*
                                    int32_t world_size, int32_t width, int32_t height, void* ldr_frame_device);
 VR_API int  vr_tonemap_allreduce_histogram(vr_tonemap* tm, void* nccl_comm);
 
+/* ---- a whole frame in one call ---------------------------------------------------- */
+/* The terrain part of Renderer::RecordCommand (Renderer.cpp:321-446: ONE command list per frame) as one entry point:
+ * vr_terrain_render(view) [RenderTargets::Clear fused when render->assume_cleared] -> vr_terrain_prepare for up to two upcoming
+ * frames -> vr_deferred_light / _tiled / _shadowed -> optionally ToneMappingPass::SimpleRender on the tone mapper's own context
+ * (reset + add_frame_to_histogram [+ vr_tonemap_allreduce_histogram] + compute_exposure + render) [+ vr_frame_allgather_ldr].
+ * It queues what those calls queue, in that order, on the same streams; it exists because a frame is otherwise about nine calls
+ * and a rank of an 8-way split of the 8K frame has a period near 0.1 ms.  When the tone mapper's context uses another stream than
+ * the terrain's, the library orders the two: the stage waits for the lighting pass, and a later lighting pass into the same
+ * hdr_out waits for the stage that still reads it (rotate two images to keep both streams busy). */
+typedef struct vr_frame_desc {
+    const vr_view*          view;               /* this frame's view (IView of Renderer::RenderScene) */
+    const vr_view*          prepare_views[2];   /* geometry of upcoming frames to build ahead; NULL = none */
+    const vr_render_params* render;
+    const vr_partition*     part;               /* NULL = whole frame */
+    const vr_light*         lights;
+    int32_t                 num_lights;
+    int32_t                 tiled;              /* 1 = vr_deferred_light_tiled (many lights) */
+    float                   ambient_top[3], ambient_bottom[3];
+    const vr_shadow_binding* shadow;            /* optional: vr_deferred_light_shadowed */
+    vr_image*               hdr_out;            /* HdrColor, or this rank's packed RGB16F tiles */
+    /* optional tone-map stage: tonemap NULL = none */
+    struct vr_tonemap*      tonemap;
+    const vr_tonemap_params* tonemap_params;
+    float                   frame_time_seconds;
+    int32_t                 reserved0;
+    void*                   ldr_out;            /* device: LdrColor SRGBA8, or this rank's packed RGB8 tiles */
+    size_t                  ldr_capacity;
+    /* optional exchange behind it (N ranks; all NULL = none): the host's ncclComm_t, world x packed bytes, the whole SRGBA8 frame */
+    void*                   nccl_comm;
+    void*                   gathered;
+    void*                   ldr_frame;
+} vr_frame_desc;
+VR_API int vr_frame_submit(vr_terrain* t, vr_gbuffer* gb, const vr_frame_desc* frame);
+
 /* ---- synthetic inputs (media/ is absent from the reference checkout;
  * SURVEY §8d): seeded integer-hash fBm heightmap and banded albedo, generated on
  * the device and copied to host buffers. ------------------------------------------ */

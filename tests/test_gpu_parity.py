@@ -1238,6 +1238,73 @@ def test_bench_n_rank_path_through_rccl_and_the_c_abi(mode):
     assert out["sustained"]["value"] > 0
 
 
+@pytest.mark.parametrize("cross_stream", [False, True])
+def test_frame_submit_equals_the_per_call_sequence(scene256, oracle, gpu_ctx, cross_stream):
+    """vr_frame_submit queues what Render + Prepare x 2 + Light + the tone-map stage queue: six frames in flight (no host
+    synchronisation in between, two rotating tile/image buffers, the tone mapper on the terrain's stream or on its own) give
+    the same HdrColor and LdrColor bytes as the per-call sequence - the first frame against the oracle as well."""
+    import torch
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 512, 288
+    views = [vr.make_view(*scaled_camera(CAMERAS[k], 256), w, h) for k in (0, 1, 5, 3, 0, 6)]
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    lights = [vr.reference_sun()]
+    tmp = vr.default_tonemap_params()
+    side = torch.cuda.Stream() if cross_stream else None
+    tctx = vr.Context(0) if cross_stream else gpu_ctx
+    if cross_stream:
+        tctx.set_stream(side.cuda_stream)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    hdrs = [vr.HdrImage(gpu_ctx, w, h) for _ in range(2)]
+    ldrs = [vr.LdrImage(tctx, w, h) for _ in range(2)]
+
+    def run(submit):
+        tm = vr.ToneMappingPass(tctx)
+        tm.AdvanceFrame(1.0 / 60.0)
+        fr = vr.Frame(tp, rt, rp, lights, AMBIENT_TOP, AMBIENT_BOTTOM, tonemap=tm, tonemap_params=tmp, ldr=ldrs[0]) if submit else None
+        outs = []
+        for i, v in enumerate(views):
+            b = i % 2
+            if i >= 2:                                  # the host reads a buffer back before its slot is used again
+                gpu_ctx.synchronize(); tctx.synchronize()
+                outs.append((hdrs[b].download().copy(), ldrs[b].download().copy()))
+            if submit:
+                fr.submit(v, hdrs[b], views[i + 1:i + 3], ldr=ldrs[b])
+            else:
+                tp.Render(v, v, rt, rp)
+                for nv in views[i + 1:i + 3]:
+                    tp.Prepare(nv, rt, rp)
+                vr.DeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdrs[b])
+                if cross_stream:
+                    gpu_ctx.synchronize()               # the per-call reference orders the two streams the blunt way
+                tm.SimpleRender(tmp, hdrs[b], ldrs[b])
+                if cross_stream:
+                    tctx.synchronize()
+        gpu_ctx.synchronize(); tctx.synchronize()
+        for b in (0, 1):
+            outs.append((hdrs[b].download().copy(), ldrs[b].download().copy()))
+        tm.close()
+        return outs
+    try:
+        want, got = run(False), run(True)
+        assert len(want) == len(got) == len(views)
+        for k, ((h0, l0), (h1, l1)) in enumerate(zip(want, got)):
+            assert np.array_equal(h0, h1), f"HdrColor of frame slot {k} differs"
+            assert np.array_equal(l0, l1), f"LdrColor of frame slot {k} differs"
+        gb = oracle.GBufferHost(w, h)
+        ot.render(views[0], gb, vr.default_render_params(400.0))
+        ref = oracle.deferred(views[0], gb, lights, AMBIENT_TOP, AMBIENT_BOTTOM)
+        a, b_ = oracle.half_to_float(got[0][0]).astype(np.float64), oracle.half_to_float(ref).astype(np.float64)
+        assert np.sqrt(np.mean((a - b_) ** 2)) <= 1e-4
+    finally:
+        if cross_stream:
+            torch.cuda.synchronize()
+        for o in ldrs + hdrs + [rt]:
+            o.close()
+        if cross_stream:
+            tctx.close()
+
+
 def _render_view_both(sc, oracle, gpu_ctx, v, w, h, **rpkw):
     ot, tp = sc["ot"], sc["tp"]
     rp = vr.default_render_params(400.0, **rpkw)

@@ -13,7 +13,7 @@ CSRC = os.path.join(_DIR, "csrc")
 LIB_DIR = os.path.join(_DIR, "lib")
 OBJ_DIR = os.path.join(_DIR, "build")
 LIB = os.path.join(LIB_DIR, "libvrterrain.so")
-SOURCES = ["vr_host.hip", "vr_tex.hip", "vr_select.hip", "vr_raster.hip", "vr_deferred.hip", "vr_tonemap.hip", "vr_comm.hip"]
+SOURCES = ["vr_host.hip", "vr_tex.hip", "vr_select.hip", "vr_raster.hip", "vr_deferred.hip", "vr_tonemap.hip", "vr_comm.hip", "vr_frame.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 

@@ -121,8 +121,19 @@ class TonemapParams(C.Structure):
         "max_log_luminance")]
 
 
+class FrameDesc(C.Structure):
+    """vr_frame_desc: one frame for vr_frame_submit (pointers as c_void_p; the Python side keeps the objects alive)."""
+    _fields_ = [("view", C.c_void_p), ("prepare_views", C.c_void_p * 2), ("render", C.c_void_p), ("part", C.c_void_p),
+                ("lights", C.c_void_p), ("num_lights", C.c_int32), ("tiled", C.c_int32),
+                ("ambient_top", C.c_float * 3), ("ambient_bottom", C.c_float * 3), ("shadow", C.c_void_p), ("hdr_out", C.c_void_p),
+                ("tonemap", C.c_void_p), ("tonemap_params", C.c_void_p), ("frame_time_seconds", C.c_float), ("reserved0", C.c_int32),
+                ("ldr_out", C.c_void_p), ("ldr_capacity", C.c_size_t), ("nccl_comm", C.c_void_p), ("gathered", C.c_void_p),
+                ("ldr_frame", C.c_void_p)]
+
+
 assert C.sizeof(Instance) == 112
 assert C.sizeof(Light) == 64
+assert C.sizeof(FrameDesc) == 160
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvrterrain.so")
@@ -142,7 +153,7 @@ EXPORTS = [
     "vr_shadow_default_params", "vr_shadow_view_setup", "vr_deferred_light_shadowed",
     "vr_tonemap_default_params", "vr_tonemap_create", "vr_tonemap_destroy", "vr_tonemap_reset_exposure", "vr_tonemap_reset_histogram",
     "vr_tonemap_add_frame_to_histogram", "vr_tonemap_histogram_device_ptr", "vr_tonemap_compute_exposure", "vr_tonemap_render",
-    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_allgather", "vr_frame_allgather_tiles", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_tile_order", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
+    "vr_tonemap_simple_render", "vr_tonemap_download", "vr_partition_packed_bytes_ldr", "vr_frame_detile_ldr", "vr_frame_submit", "vr_frame_allgather", "vr_frame_allgather_tiles", "vr_frame_allgather_ldr", "vr_tonemap_allreduce_histogram", "vr_synth_heightmap", "vr_synth_albedo", "vr_debug_srgb_encode", "vr_debug_fastmath_check", "vr_debug_render_stats", "vr_debug_tile_order", "vr_debug_download_vertices", "vr_terrain_memory_bytes",
 ]
 
 _lib = None
@@ -228,6 +239,7 @@ def load_library():
         "vr_frame_allgather": (C.c_int, [vp, vp, vp, vp, C.c_int32, vp]),
         "vr_frame_allgather_ldr": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
         "vr_frame_allgather_tiles": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_size_t]),
+        "vr_frame_submit": (C.c_int, [vp, vp, P(FrameDesc)]),
         "vr_tonemap_allreduce_histogram": (C.c_int, [vp, vp]),
         "vr_shadow_default_params": (None, [P(ShadowParams), C.c_float]),
         "vr_shadow_view_setup": (C.c_int, [P(Light), P(View), P(ShadowParams), P(View)]),

@@ -552,7 +552,11 @@ extern "C" VR_API int vr_image_create(vr_context* ctx, int32_t w, int32_t h, voi
 extern "C" VR_API void vr_image_destroy(vr_image* im)
 {
     if (!im) return;
-    if (im->owned) { (void)hipSetDevice(im->ctx->device); (void)hipFree(im->data); }
+    (void)hipSetDevice(im->ctx->device);
+    if (im->read_pending) (void)hipEventSynchronize(im->ev_read_done);       // a stage on another stream may still be reading it
+    if (im->ev_written) (void)hipEventDestroy(im->ev_written);
+    if (im->ev_read_done) (void)hipEventDestroy(im->ev_read_done);
+    if (im->owned) (void)hipFree(im->data);
     delete im;
 }
 extern "C" VR_API void* vr_image_device_ptr(vr_image* im) { return im ? im->data : nullptr; }

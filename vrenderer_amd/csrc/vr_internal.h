@@ -214,6 +214,10 @@ struct vr_image {
     void* data;
     bool owned;
     size_t capacity_bytes;
+    // vr_frame_submit's cross-stream bookkeeping: the lighting pass that wrote the image (when no dispatch-stamped event exists)
+    // and the stage on another stream that still reads it
+    hipEvent_t ev_written = nullptr, ev_read_done = nullptr;
+    bool read_pending = false;
 };
 
 struct vr_ldr_image {

@@ -512,6 +512,50 @@ class CascadedShadowMap:
         self.targets.close()
 
 
+class Frame:
+    """One frame for vr_frame_submit - the terrain part of Renderer::RecordCommand (Renderer.cpp:321-446) as one call: Render
+    [Clear fused] -> Prepare for up to two upcoming frames -> lighting -> optional tone-map stage [-> exchange].  Everything
+    that does not change from frame to frame (lights, ambient terms, render parameters, partition, tone mapper, buffers) is
+    set once; submit() fills in the views and the output image and makes the one call."""
+
+    def __init__(self, terrain_pass, render_targets, render_params, lights, ambient_top, ambient_bottom, partition=None, tiled=False,
+                 tonemap=None, tonemap_params=None, ldr=None, comm=None, gathered_ptr=None, ldr_frame=None):
+        self.tp, self.rt = terrain_pass, render_targets
+        self._keep = (render_params, light_array(lights), partition, tonemap, tonemap_params, ldr, comm, ldr_frame)
+        d = capi.FrameDesc()
+        d.render = C.addressof(render_params)
+        d.part = C.addressof(partition) if partition is not None else None
+        d.lights = C.addressof(self._keep[1])
+        d.num_lights = len(lights)
+        d.tiled = 1 if tiled else 0
+        d.ambient_top[:] = [float(x) for x in ambient_top]
+        d.ambient_bottom[:] = [float(x) for x in ambient_bottom]
+        if tonemap is not None:
+            d.tonemap = tonemap.handle
+            d.tonemap_params = C.addressof(tonemap_params)
+            d.frame_time_seconds = tonemap.frame_time
+            d.ldr_out = ldr.device_ptr
+            d.ldr_capacity = ldr.capacity
+            if comm is not None:
+                d.nccl_comm = getattr(comm, "handle", comm)
+                d.gathered = gathered_ptr
+                d.ldr_frame = ldr_frame.device_ptr
+        self.desc = d
+        self._submit = terrain_pass.ctx.lib.vr_frame_submit
+
+    def submit(self, view, hdr_out, prepare=(), ldr=None):
+        d = self.desc
+        d.view = C.addressof(view)
+        d.prepare_views[0] = C.addressof(prepare[0]) if len(prepare) > 0 else None
+        d.prepare_views[1] = C.addressof(prepare[1]) if len(prepare) > 1 else None
+        d.hdr_out = hdr_out.handle
+        if ldr is not None:
+            d.ldr_out, d.ldr_capacity = ldr.device_ptr, ldr.capacity
+        rc = self._submit(self.tp.handle, self.rt.handle, C.byref(d))
+        if rc:
+            check(rc, "vr_frame_submit")
+
+
 def light_array(lights):
     """The contiguous vr_light[] the C ABI takes, built once: a host that keeps its lights in such an array (as the
     reference keeps them in its scene graph) does not convert a Python list per frame.  Render() accepts either."""
