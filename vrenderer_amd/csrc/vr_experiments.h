@@ -11,7 +11,7 @@
 #if !defined(VR_EXPERIMENT_BUILD)
 #if defined(VR_EXP_FAST_SAMEADDR) || defined(VR_EXP_FAST_ALB1) || defined(VR_EXP_FAST_HGT1) || defined(VR_EXP_FAST_NOLEVEL1) || \
     defined(VR_EXP_TILED_STORES) || defined(VR_EXP_NOSTORE) || defined(VR_EXP_NOEMISSIVE) || defined(VR_EXP_NORECORD) || \
-    defined(VR_EXP_NOENCODE) || defined(VR_RASTER_PROFILE) || defined(VR_SELECT_PROFILE)
+    defined(VR_EXP_NOENCODE) || defined(VR_EXP_NOTABLES) || defined(VR_RASTER_PROFILE) || defined(VR_SELECT_PROFILE)
 #error "VR_EXP_* / VR_*_PROFILE switches produce wrong images or instrumented kernels: they need -DVR_EXPERIMENT_BUILD (tools/build_variant.py)"
 #endif
 #endif
@@ -61,6 +61,11 @@ constexpr bool kExpNoEncode = true;
 #else
 constexpr bool kExpNoEncode = false;
 #endif
+#ifdef VR_EXP_NOTABLES          // the tile pass's small tables (sRGB encode, level table) are not fetched from memory per workgroup (zeros instead)
+constexpr bool kExpNoTables = true;
+#else
+constexpr bool kExpNoTables = false;
+#endif
 #ifdef VR_RASTER_PROFILE
 constexpr bool kExpRasterProfile = true;
 #else
@@ -74,7 +79,7 @@ constexpr bool kExpSelectProfile = false;
 
 constexpr unsigned kExpMask = (kExpSameAddr ? 1u : 0u) | (kExpOneAlbedo ? 2u : 0u) | (kExpOneHeight ? 4u : 0u) | (kExpNoLevel1 ? 8u : 0u)
                             | (kExpTiledStores ? 16u : 0u) | (kExpNoStore ? 32u : 0u) | (kExpNoEmissive ? 64u : 0u) | (kExpNoRecord ? 128u : 0u)
-                            | (kExpNoEncode ? 256u : 0u) | (kExpRasterProfile ? 0x10000u : 0u) | (kExpSelectProfile ? 0x20000u : 0u)
+                            | (kExpNoEncode ? 256u : 0u) | (kExpNoTables ? 512u : 0u) | (kExpRasterProfile ? 0x10000u : 0u) | (kExpSelectProfile ? 0x20000u : 0u)
 #ifdef VR_EXPERIMENT_BUILD
                             | 0x80000000u
 #endif

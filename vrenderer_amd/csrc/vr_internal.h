@@ -113,6 +113,24 @@ static_assert(sizeof(DevVert) == 48, "DevVert layout");
 struct HardTriRec { uint32_t v0, v1, v2, order_key; uint32_t rect_lo, rect_hi, pad0, pad1; };
 static_assert(sizeof(HardTriRec) == 32, "HardTriRec layout");
 
+// Bin entry (round 4): a triangle as ONE raster tile sees it, set up once by k_fill - per (triangle, tile) pair, one lane each,
+// full waves - instead of by every tile-pass workgroup from the triangle's record: edge functions at the centre of the tile's
+// pixel (0, 0) and their steps per pixel, the triangle's pixel box inside the tile, the depth plane with the tile's origin
+// relative to the plane's anchor, and the draw-order word of the visibility buffer.  64 bytes = four 16-byte groups, so that
+// a sparse bin's entries can be read with scalar loads (the entry index is wave-uniform) straight into SGPRs: no per-lane
+// record fetch, no per-lane set-up, no v_readlane broadcast in the tile pass.
+struct TileEntry {
+    int32_t e0, e1, e2;                    // E_i at the tile's first pixel centre (bias NOT subtracted); exact when kTeFits32 is set
+    int32_t sx0, sy0, sx1, sy1, sx2, sy2;  // steps per pixel: A_i * 256, B_i * 256
+    uint32_t box;                          // x0 | y0 << 8 | x1 << 16 | y1 << 24, tile-local, inclusive (clamped to tile and viewport)
+    float z0, zx, zy;                      // depth plane about the triangle's anchor pixel
+    uint32_t offs;                         // (tile origin - anchor): x & 0xffff | y << 16
+    uint32_t order;                        // ~(key + 1): low word of the visibility buffer
+    uint32_t flags;                        // bias0..2 (bits 0-2), kTeFits32, kTeValid, kTeSmall
+};
+static_assert(sizeof(TileEntry) == 64, "TileEntry layout");
+constexpr uint32_t kTeFits32 = 8u, kTeValid = 16u, kTeSmall = 32u;     // kTeSmall: every |A_i|, |B_i| <= 2^14 (the row hand-out's 24-bit products)
+
 // Screen-tile partition of a w x h frame for one rank of `world`: built once, immutable afterwards.
 struct PartTables {
     int w = 0, h = 0, rank = 0, world = 1;
@@ -246,7 +264,7 @@ struct GeoSet {
     uint32_t* d_tile_offset = nullptr;
     uint32_t* d_tile_cursor = nullptr;
     int32_t* d_tile_order = nullptr;     // launch order of the tile pass: this frame's tiles by falling bin length
-    uint32_t* d_bin_entries = nullptr;
+    TileEntry* d_bin_entries = nullptr;   // bin_capacity entries of 64 B (k_fill)
     int scratch_tiles = 0;
     int last_tiles = 0;                  // raster tiles of the target the last chain was built for (the stride of d_tile_order's class regions)
     hipEvent_t ev_geo_done = nullptr, ev_raster_done = nullptr;

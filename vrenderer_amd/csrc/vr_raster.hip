@@ -331,14 +331,65 @@ __device__ __forceinline__ uint64_t triangle_rect(const RasterArgs& a, ScreenVer
     return pack_rect(tx0, ty0, tx1, ty1);
 }
 
+// The coverage part of a triangle record (groups 0-4) as k_fill holds it while it writes the triangle's bin entries.
+struct TriCov {
+    int32_t A0, B0, A1, B1, A2, B2;
+    int64_t C0, C1, C2;
+    float z0, zx, zy;
+    uint32_t flags;                    // bias0..2, bit 3 = small
+    int bx0, by0, bx1, by1;            // pixel box (viewport-clamped); (bx0, by0) = the planes' anchor
+};
+__device__ __forceinline__ int64_t edge_eval(int32_t A, int32_t B, int64_t C, int32_t PX, int32_t PY);
+__device__ __forceinline__ int64_t rec_c(const uint4& g);
+__device__ __forceinline__ uint32_t order_of(uint32_t key);
+__device__ __forceinline__ TriCov load_tri_cov(const uint4* __restrict__ rp)
+{
+    const uint4 g0 = rp[0], g1 = rp[1], g2 = rp[2], g3 = rp[3], g4 = rp[4];
+    TriCov c;
+    c.A0 = (int32_t)g0.x; c.B0 = (int32_t)g0.y; c.A1 = (int32_t)g1.x; c.B1 = (int32_t)g1.y; c.A2 = (int32_t)g2.x; c.B2 = (int32_t)g2.y;
+    c.C0 = rec_c(g0); c.C1 = rec_c(g1); c.C2 = rec_c(g2);
+    c.z0 = __uint_as_float(g3.x); c.zx = __uint_as_float(g3.y); c.zy = __uint_as_float(g3.z); c.flags = g3.w;
+    c.bx0 = (int)(g4.x & 0xffffu); c.by0 = (int)(g4.x >> 16); c.bx1 = (int)(g4.y & 0xffffu); c.by1 = (int)(g4.y >> 16);
+    return c;
+}
+// The triangle as raster tile (tx, ty) sees it (TileEntry, vr_internal.h): what every tile-pass workgroup used to derive per lane
+// from the record - the same integer expressions, so coverage is bit for bit what it was.
+__device__ __forceinline__ void write_tile_entry(const RasterArgs& a, TileEntry* __restrict__ dst, const TriCov& c, uint32_t key, int tx, int ty)
+{
+    const int tile = 1 << a.tile_shift;
+    const int ox = tx << a.tile_shift, oy = ty << a.tile_shift;
+    const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;                       // centre of the tile's pixel (0, 0)
+    const int64_t e0 = edge_eval(c.A0, c.B0, c.C0, PX0, PY0), e1 = edge_eval(c.A1, c.B1, c.C1, PX0, PY0), e2 = edge_eval(c.A2, c.B2, c.C2, PX0, PY0);
+    const int lx0 = max(ox, a.vx0), ly0 = max(oy, a.vy0), lx1 = min(ox + tile - 1, a.vx1), ly1 = min(oy + tile - 1, a.vy1);
+    const int x0 = max(c.bx0, lx0) - ox, y0 = max(c.by0, ly0) - oy, x1 = min(c.bx1, lx1) - ox, y1 = min(c.by1, ly1) - oy;
+    const bool valid = x0 <= x1 && y0 <= y1;            // (never empty for a binned triangle; checked all the same)
+    bool fits32 = (c.flags & 8u) != 0u;                  // small: every edge value over the tile fits 31 bits (write_tri_rec)
+    if (!fits32) {
+        const int64_t lim = (int64_t)1 << 30;
+        const int64_t w0 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)c.A0) + llabs((int64_t)c.B0));
+        const int64_t w1 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)c.A1) + llabs((int64_t)c.B1));
+        const int64_t w2 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)c.A2) + llabs((int64_t)c.B2));
+        fits32 = llabs(e0) + w0 < lim && llabs(e1) + w1 < lim && llabs(e2) + w2 < lim;
+    }
+#define MUL256(v) ((uint32_t)(v) * 256u)      // (unsigned: the products of a triangle that does not fit are never used, but must not be undefined)
+    uint4* __restrict__ q = reinterpret_cast<uint4*>(dst);
+    q[0] = make_uint4((uint32_t)e0, (uint32_t)e1, (uint32_t)e2, MUL256(c.A0));
+    q[1] = make_uint4(MUL256(c.B0), MUL256(c.A1), MUL256(c.B1), MUL256(c.A2));
+    q[2] = make_uint4(MUL256(c.B2), valid ? ((uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24)) : 0u,
+                      __float_as_uint(c.z0), __float_as_uint(c.zx));
+    q[3] = make_uint4(__float_as_uint(c.zy), ((uint32_t)(ox - c.bx0) & 0xffffu) | ((uint32_t)(oy - c.by0) << 16), order_of(key),
+                      (c.flags & 7u) | (fits32 ? kTeFits32 : 0u) | (valid ? kTeValid : 0u) | ((c.flags & 8u) ? kTeSmall : 0u));
+#undef MUL256
+}
+
 // Adds `r`'s triangle to the per-tile counters (FILL = false) or claims its bin slots and writes
-// `entry` (FILL = true).  Neighbouring triangles of a terrain tile mostly land in the same raster
+// its entries (FILL = true: `cov` = the triangle's coverage record, `entry` = its draw-order key).  Neighbouring triangles of a terrain tile mostly land in the same raster
 // tile, so the common single-tile case is aggregated per wave: lanes that target the same tile elect
 // a leader (ballot + readlane), which issues ONE atomic for all of them.  Must be called by every
 // lane that is still in the caller's loop (wave-level operations inside).
 template <bool FILL>
 __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32_t entry, uint32_t* __restrict__ counters_or_cursor,
-                                         uint32_t* __restrict__ entries)
+                                         TileEntry* __restrict__ entries, const TriCov& cov)
 {
     const int tx0 = (int)(r & 0xffffu), ty0 = (int)((r >> 16) & 0xffffu), tx1 = (int)((r >> 32) & 0xffffu), ty1 = (int)((r >> 48) & 0xffffu);
     const bool live = r != ~0ull;
@@ -357,7 +408,7 @@ __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
             if (tile == t) {
                 const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                if (pos < a.bin_capacity) entries[pos] = entry;
+                if (pos < a.bin_capacity) write_tile_entry(a, entries + pos, cov, entry, tx0, ty0);
             }
         }
         todo &= ~same;
@@ -374,13 +425,13 @@ __device__ __forceinline__ void bin_rect(const RasterArgs& a, uint64_t r, uint32
                 pos[q] = use[q] ? atomicAdd(&counters_or_cursor[ty * a.rtx + tx], 1u) : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (use[q] && pos[q] < a.bin_capacity) entries[pos[q]] = entry;
+            for (int q = 0; q < 4; q++) if (use[q] && pos[q] < a.bin_capacity) write_tile_entry(a, entries + pos[q], cov, entry, tx0 + (q & 1), ty0 + (q >> 1));
         } else
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++)
                 if (tile_owned(a, tx, ty)) {
                     const uint32_t pos = atomicAdd(&counters_or_cursor[ty * a.rtx + tx], 1u);
-                    if (FILL && pos < a.bin_capacity) entries[pos] = entry;
+                    if (FILL && pos < a.bin_capacity) write_tile_entry(a, entries + pos, cov, entry, tx, ty);
                 }
     }
 }
@@ -583,7 +634,8 @@ __global__ __launch_bounds__(256) void k_scan(int n_tiles, uint32_t* __restrict_
     }
 }
 // The tile of the tile pass's workgroup `i`: classes in falling bin length, class c's tiles at order[c * stride ...].
-__device__ __forceinline__ int tile_of_block(int i, const int32_t* __restrict__ order, const uint32_t* __restrict__ class_totals, int stride)
+template <typename OP, typename CP>
+__device__ __forceinline__ int tile_of_block(int i, OP order, CP class_totals, int stride)
 {
     int c = 0;
 #pragma unroll
@@ -627,7 +679,7 @@ __global__ __launch_bounds__(256) void k_setup(RasterArgs a, const DevVert* __re
                 r = triangle_rect(a, load_sv(verts, i0), load_sv(verts, i1), load_sv(verts, i2), recs + (size_t)tri * kRecGroups);
             }
         }
-        bin_rect<false>(a, r, 0u, tile_count, nullptr);
+        bin_rect<false>(a, r, 0u, tile_count, nullptr, TriCov());
         rect[tri] = r;
     }
 }
@@ -647,23 +699,27 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// k_fill: write bin entries.  Entry = draw-order key: (triangle id << 4) | (sub << 1) | hard.
+// k_fill: write bin entries - one TileEntry per (triangle, raster tile) pair: the triangle set up against that tile, with its
+// draw-order key (triangle id << 4) | (sub << 1) | hard.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __restrict__ counters, const uint64_t* __restrict__ rect,
-                                               const HardTriRec* __restrict__ hard_tris,
-                                               uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries)
+                                               const HardTriRec* __restrict__ hard_tris, const uint4* __restrict__ recs, uint32_t rec_hard_base,
+                                               uint32_t* __restrict__ tile_cursor, TileEntry* __restrict__ entries)
 {
     VR_GEOMETRY_PRIORITY();
     const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     const uint32_t n_hard = min(counters[C_HARDTRIS], a.hard_cap * 4u);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reg + n_hard; i += gridDim.x * blockDim.x) {
-        uint64_t r; uint32_t entry;
-        if (i < n_reg) { r = rect[i]; entry = i << 4; }
+        uint64_t r; uint32_t entry; size_t rec;
+        if (i < n_reg) { r = rect[i]; entry = i << 4; rec = i; }
         else {
-            const HardTriRec rec = hard_tris[i - n_reg];
-            r = (uint64_t)rec.rect_lo | ((uint64_t)rec.rect_hi << 32); entry = rec.order_key;
+            const HardTriRec h = hard_tris[i - n_reg];
+            r = (uint64_t)h.rect_lo | ((uint64_t)h.rect_hi << 32); entry = h.order_key;
+            rec = (size_t)rec_hard_base + (i - n_reg);       // the clipper's records, in the order of its sub-triangles (clip_hard_list)
         }
-        bin_rect<true>(a, r, entry, tile_cursor, entries);
+        TriCov cov = TriCov();
+        if (r != ~0ull) cov = load_tri_cov(recs + rec * kRecGroups);
+        bin_rect<true>(a, r, entry, tile_cursor, entries, cov);
     }
 }
 
@@ -671,14 +727,16 @@ __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __re
 // k_raster: one workgroup per 64x64 (or 32x32) raster tile
 // ---------------------------------------------------------------------------------------
 // record index of a bin entry: the triangle id, or - for clipper output - its slot in the records' extra region
-__device__ __forceinline__ size_t rec_index(uint32_t key, const uint32_t* __restrict__ hard_first, uint32_t rec_hard_base)
+template <typename HF>
+__device__ __forceinline__ size_t rec_index(uint32_t key, HF hard_first, uint32_t rec_hard_base)
 {
     const uint32_t tri = key >> 4;
     if (key & 1u) return (size_t)rec_hard_base + hard_first[tri] + ((key >> 1) & 7u);
     return (size_t)tri;
 }
 
-__device__ __forceinline__ void entry_vertices(uint32_t key, const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
+template <typename HF>
+__device__ __forceinline__ void entry_vertices(uint32_t key, const HardTriRec* __restrict__ hard_tris, HF hard_first,
                                                uint32_t& i0, uint32_t& i1, uint32_t& i2)
 {
     const uint32_t tri = key >> 4;
@@ -985,6 +1043,10 @@ constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels whe
 #define VR_ROW_MIN 8
 #endif
 constexpr int kRowMin = VR_ROW_MIN;  // the row hand-out needs this many eligible triangles in a wave (its scan + fetches are a fixed cost)
+#ifndef VR_SPARSE_MAX
+#define VR_SPARSE_MAX 48
+#endif
+constexpr int kSparseMax = VR_SPARSE_MAX;   // bins up to this long are walked entry by entry with scalar loads (k_raster's coverage)
 constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)
 
 // The depth plane of a triangle as the coverage sweeps carry it: coefficients + the tile's origin relative to the anchor
@@ -1144,7 +1206,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
-                                                 const uint32_t* __restrict__ entries, const int32_t* __restrict__ tile_list,
+                                                 const TileEntry* __restrict__ entries, const int32_t* __restrict__ tile_list,
                                                  const uint32_t* __restrict__ tile_classes,
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
@@ -1162,9 +1224,8 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
     if (tile < 0 || tile >= a.rtx * a.rty) return;              // never index the bins or the targets with a foreign tile id
     // Everything the workgroup needs from memory before its first sweep is requested HERE, at once, and used after the
-    // visibility buffer's set-up: the small tables, the bin's bounds and its first 256 entries (their records follow behind the
-    // barrier: held across it they cost twenty registers and the 32-pixel variant a workgroup per CU).  Written in program order (table, wait, LDS store,
-    // next table, ..., barrier, bounds, entries, records) the prologue was eight dependent round trips per workgroup,
+    // visibility buffer's set-up: the small tables and the bin's bounds.  Written in program order (table, wait, LDS store,
+    // next table, ..., barrier, bounds, entries) the prologue was eight dependent round trips per workgroup,
     // a fifth of a 32-pixel tile's time (4K: init + record fetch = 21 % of the wave cycles).
     uint4 lv_r = make_uint4(0, 0, 0, 0);
     if (MODE == RM_FAST && tid < kMaxLevels) lv_r = hm.fast_lv[tid];
@@ -1173,13 +1234,13 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     constexpr int kEncWords = (kEncTabSize + 3) / 4, kEncPer = (kEncWords + kRT - 1) / kRT;
     uint32_t enc_r[kEncPer];
 #pragma unroll
-    for (int q = 0; q < kEncPer; q++) enc_r[q] = tid + q * kRT < kEncWords ? reinterpret_cast<const uint32_t*>(enc_g)[tid + q * kRT] : 0u;
-    const float thr_r = tid < 256 ? thr_g[tid] : 0.0f;
-    const uint32_t off = tile_offset[tile], n = tile_cursor[tile] - off;     // bin = entries[off .. off + n)
+    for (int q = 0; q < kEncPer; q++) enc_r[q] = (!kExpNoTables && tid + q * kRT < kEncWords) ? reinterpret_cast<const uint32_t*>(enc_g)[tid + q * kRT] : 0u;
+    const float thr_r = (!kExpNoTables && tid < 256) ? thr_g[tid] : 0.0f;
+    const uint32_t off = tile_offset[tile], n_all = tile_cursor[tile] - off;     // bin = entries[off .. off + n_all)
+    const uint32_t n = min(n_all, off < a.bin_capacity ? a.bin_capacity - off : 0u);   // (an overflowing frame drops the entries beyond the capacity: VR_ERR_OVERFLOW)
+    const TileEntry* __restrict__ bin = entries + off;
     // consecutive bin entries go to different waves so that a short list still uses all of them
     const uint32_t idx0 = (uint32_t)(lane * kRW + wave);
-    const bool valid0 = idx0 < n && (off + idx0) < a.bin_capacity;
-    const uint32_t key0 = valid0 ? entries[off + idx0] : 0u;
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
     const int ox = txi * TILE, oy = tyi * TILE;
     // visibility buffer: existing depth (or the clear value) with the "nothing drawn" key
@@ -1207,36 +1268,77 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     __syncthreads();
     VR_PROF_MARK(0);
 
-    const int bx0 = max(ox, a.vx0), by0 = max(oy, a.vy0), bx1 = min(ox + TILE - 1, a.vx1), by1 = min(oy + TILE - 1, a.vy1);
     const int32_t PX0 = ox * 256 + 128, PY0 = oy * 256 + 128;   // centre of the tile's pixel (0,0)
-    for (uint32_t base = 0; base < n; base += kRT) {
-        const uint32_t idx = base + idx0;
-        bool valid = idx < n && (off + idx) < a.bin_capacity;
-        uint32_t key = key0;                                   // (the first batch's keys were requested in the prologue)
-        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0;
-        if (valid) {
-            if (base != 0u) key = entries[off + idx];         // (uniform) the later batches of a long bin
-            const uint4* __restrict__ rp = recs + rec_index(key, hard_first, rec_hard_base) * kRecGroups;
-            g0 = rp[0]; g1 = rp[1]; g2 = rp[2]; g3 = rp[3]; g4 = rp[4];
+    // ---- coverage.  A bin entry is the triangle already set up against THIS tile (TileEntry, written by k_fill): edge values at
+    // the tile's first pixel, steps, box, depth plane, draw-order word.  Until round 4 every workgroup derived all that per lane
+    // from the triangle's record - five 16-byte fetches behind the key's, ~250 vector instructions per wave whether the wave held
+    // two entries or sixty - and broadcast each swept triangle with ~25 v_readlane.
+    // A wide triangle (edge values beyond 31 bits over the tile: kTeFits32 clear; rare) is redone in 64 bits from its record.
+    auto sweep_wide = [&](uint32_t ord, uint32_t bx, uint32_t flags, const ZPlane& zz) {          // (wave-uniform arguments)
+        const uint32_t key = key_of(ord);
+        const uint4* __restrict__ rp = recs + rec_index(key, hard_first, rec_hard_base) * kRecGroups;
+        const uint4 g0 = rp[0], g1 = rp[1], g2 = rp[2];
+        const int64_t e0 = edge_eval((int32_t)g0.x, (int32_t)g0.y, rec_c(g0), PX0, PY0), e1 = edge_eval((int32_t)g1.x, (int32_t)g1.y, rec_c(g1), PX0, PY0),
+                      e2 = edge_eval((int32_t)g2.x, (int32_t)g2.y, rec_c(g2), PX0, PY0);
+        sweep_big<int64_t, TILE>(vis, lane, e0, e1, e2, (int64_t)(int32_t)g0.x * 256, (int64_t)(int32_t)g0.y * 256, (int64_t)(int32_t)g1.x * 256,
+                                 (int64_t)(int32_t)g1.y * 256, (int64_t)(int32_t)g2.x * 256, (int64_t)(int32_t)g2.y * 256, (int)(flags & 1u), (int)((flags >> 1) & 1u),
+                                 (int)((flags >> 2) & 1u), (int)(bx & 255u), (int)((bx >> 8) & 255u), (int)((bx >> 16) & 255u), (int)(bx >> 24), zz, ord);
+    };
+    // One (wave-uniform) entry swept by all 64 lanes: along its long axis when that is most of a tile, else in 8x8 blocks.
+    auto sweep_uniform = [&](int32_t e0, int32_t e1, int32_t e2, int32_t sx0, int32_t sy0, int32_t sx1, int32_t sy1, int32_t sx2, int32_t sy2,
+                             uint32_t bx, float z0, float zx, float zy, uint32_t bo, uint32_t ord, uint32_t flags) {
+        ZPlane bz;
+        bz.z0 = z0; bz.zx = zx; bz.zy = zy;
+        bz.offx = (int)(int16_t)(bo & 0xffffu); bz.offy = (int)(int16_t)(bo >> 16);
+        if (!(flags & kTeFits32)) { sweep_wide(ord, bx, flags, bz); return; }
+        const int b0 = flags & 1u, b1 = (flags >> 1) & 1u, b2 = (flags >> 2) & 1u;
+        const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
+        if (max(qx1 - qx0, qy1 - qy0) + 1 >= min(kWalkMin, TILE - 4))
+            sweep_walk<TILE>(vis, lane, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
+        else
+            sweep_big<int32_t, TILE>(vis, lane, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
+    };
+    if (!WIRE && n <= (uint32_t)kSparseMax) {
+        // Sparse bin (the rule at 8K: ~6 entries per 32-pixel tile): every wave walks its share of the entries, and because the entry
+        // index is wave-uniform the 64 bytes arrive through the scalar cache straight in SGPRs - the next entry requested before
+        // the current one is swept.
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+        const uint4* __restrict__ q = reinterpret_cast<const uint4*>(bin);
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+        if (w0 < n) { n0 = q[w0 * 4 + 0]; n1 = q[w0 * 4 + 1]; n2 = q[w0 * 4 + 2]; n3 = q[w0 * 4 + 3]; }
+        for (uint32_t j = w0; j < n; j += kRW) {
+            const uint4 t0 = n0, t1 = n1, t2 = n2, t3 = n3;
+            const uint32_t jn = j + kRW;
+            if (jn < n) { n0 = q[jn * 4 + 0]; n1 = q[jn * 4 + 1]; n2 = q[jn * 4 + 2]; n3 = q[jn * 4 + 3]; }
+            if (!(t3.w & kTeValid)) continue;
+            sweep_uniform((int32_t)t0.x, (int32_t)t0.y, (int32_t)t0.z, (int32_t)t0.w, (int32_t)t1.x, (int32_t)t1.y, (int32_t)t1.z, (int32_t)t1.w, (int32_t)t2.x,
+                          t2.y, __uint_as_float(t2.z), __uint_as_float(t2.w), __uint_as_float(t3.x), t3.y, t3.z, t3.w);
         }
-        const int32_t A0 = (int32_t)g0.x, B0 = (int32_t)g0.y, A1 = (int32_t)g1.x, B1 = (int32_t)g1.y, A2 = (int32_t)g2.x, B2 = (int32_t)g2.y;
-        const int64_t C0 = rec_c(g0), C1 = rec_c(g1), C2 = rec_c(g2);
-        const int bias0 = (int)(g3.w & 1u), bias1 = (int)((g3.w >> 1) & 1u), bias2 = (int)((g3.w >> 2) & 1u);
-        const bool is_small = (g3.w & 8u) != 0u;
-        // the depth plane, with this tile's origin relative to the plane's anchor (the box's first pixel)
+        VR_PROF_MARK(4);
+    } else
+    for (uint32_t base = 0; base < n; base += kRT) {
+        // Dense bin (low resolutions, distant terrain): one lane per entry; tiny triangles are rasterised by their lane, small ones
+        // handed out row by row, the rest broadcast and swept by the wave.
+        const uint32_t idx = base + idx0;
+        bool valid = idx < n;
+        uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0, t3 = t0;
+        if (valid) { const uint4* __restrict__ q = reinterpret_cast<const uint4*>(bin + idx); t0 = q[0]; t1 = q[1]; t2 = q[2]; t3 = q[3]; }
+        const int32_t e0 = (int32_t)t0.x, e1 = (int32_t)t0.y, e2 = (int32_t)t0.z;
+        const int32_t sx0 = (int32_t)t0.w, sy0 = (int32_t)t1.x, sx1 = (int32_t)t1.y, sy1 = (int32_t)t1.z, sx2 = (int32_t)t1.w, sy2 = (int32_t)t2.x;
+        const uint32_t box = t2.y, offs = t3.y, order = t3.z, flags = t3.w;
+        const int bias0 = (int)(flags & 1u), bias1 = (int)((flags >> 1) & 1u), bias2 = (int)((flags >> 2) & 1u);
+        const bool fits32 = (flags & kTeFits32) != 0u, is_small = (flags & kTeSmall) != 0u;
         ZPlane zp;
-        zp.z0 = __uint_as_float(g3.x); zp.zx = __uint_as_float(g3.y); zp.zy = __uint_as_float(g3.z);
-        zp.offx = ox - (int)(g4.x & 0xffffu); zp.offy = oy - (int)(g4.x >> 16);
-        // the triangle's pixel box inside this tile (never empty for a binned triangle; checked all the same)
-        const int tx0 = max((int)(g4.x & 0xffffu), bx0), ty0 = max((int)(g4.x >> 16), by0);
-        const int tx1 = min((int)(g4.y & 0xffffu), bx1), ty1 = min((int)(g4.y >> 16), by1);
-        valid = valid && tx0 <= tx1 && ty0 <= ty1;
-        const uint32_t order = order_of(key);
+        zp.z0 = __uint_as_float(t2.z); zp.zx = __uint_as_float(t2.w); zp.zy = __uint_as_float(t3.x);
+        zp.offx = (int)(int16_t)(offs & 0xffffu); zp.offy = (int)(int16_t)(offs >> 16);
+        valid = valid && (flags & kTeValid) != 0u;
+        const int x0 = (int)(box & 255u), y0 = (int)((box >> 8) & 255u), x1 = (int)((box >> 16) & 255u), y1 = (int)(box >> 24);      // tile-local, inclusive
         if (WIRE) {
             if (valid) {
                 uint32_t i0, i1, i2;
-                entry_vertices(key, hard_tris, hard_first, i0, i1, i2);
+                entry_vertices(key_of(order), hard_tris, hard_first, i0, i1, i2);
                 const ScreenVert s0 = load_sv(verts, i0), s1 = load_sv(verts, i1), s2 = load_sv(verts, i2);
+                const int tx0 = x0 + ox, ty0 = y0 + oy, tx1 = x1 + ox, ty1 = y1 + oy;
                 wire_edge<TILE>(vis, s0.X, s0.Y, s1.X, s1.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
                 wire_edge<TILE>(vis, s1.X, s1.Y, s2.X, s2.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
                 wire_edge<TILE>(vis, s2.X, s2.Y, s0.X, s0.Y, zp, ox, oy, tx0, ty0, tx1, ty1, order);
@@ -1244,32 +1346,12 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
             continue;                   // covered; no fill sweeps
         }
         VR_PROF_MARK(1);
-        // tile-relative form
-        const int64_t e0 = edge_eval(A0, B0, C0, PX0, PY0), e1 = edge_eval(A1, B1, C1, PX0, PY0), e2 = edge_eval(A2, B2, C2, PX0, PY0);
-        const int x0 = tx0 - ox, y0 = ty0 - oy, x1 = tx1 - ox, y1 = ty1 - oy;      // tile-local, inclusive
         const int bw = valid ? x1 - x0 + 1 : 0, bh = valid ? y1 - y0 + 1 : 0;
-        // One lane per triangle pays when the wave's lanes are mostly busy (dense bins: low resolutions, distant terrain)
-        // or the box is tiny; everything else is handed out row by row (small triangles) or swept by the whole wave.
+        // One lane per triangle pays when the wave's lanes are mostly busy or the box is tiny; everything else is handed out row by
+        // row (small triangles) or swept by the whole wave.
         const int n_wave = __popcll(__ballot(valid));
-        const bool tiny = valid && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
-        // int32 steps (x 256 exact in 32 bits for every small triangle)
-        // (unsigned arithmetic: the products of a triangle that does not fit are never used, but must not be undefined)
-#define MUL256(v) ((int32_t)((uint32_t)(v) * 256u))
-        const int32_t sx0 = MUL256(A0), sy0 = MUL256(B0), sx1 = MUL256(A1), sy1 = MUL256(B1), sx2 = MUL256(A2), sy2 = MUL256(B2);
-        bool fits32 = is_small;
-        if (valid && !is_small) {
-            const int64_t lim = (int64_t)1 << 30;
-            const int64_t w0 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A0) + llabs((int64_t)B0));
-            const int64_t w1 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A1) + llabs((int64_t)B1));
-            const int64_t w2 = (int64_t)(kRasterTile + 8) * 256 * (llabs((int64_t)A2) + llabs((int64_t)B2));
-            fits32 = llabs(e0) + w0 < lim && llabs(e1) + w1 < lim && llabs(e2) + w2 < lim;
-        }
-        if (tiny) {
-            if (fits32) sweep_small<int32_t, TILE>(vis, (int32_t)e0, (int32_t)e1, (int32_t)e2, sx0, sy0, sx1, sy1, sx2, sy2,
-                                                    bias0, bias1, bias2, x0, y0, x1, y1, zp, order);
-            else sweep_small<int64_t, TILE>(vis, e0, e1, e2, (int64_t)A0 * 256, (int64_t)B0 * 256, (int64_t)A1 * 256, (int64_t)B1 * 256,
-                                             (int64_t)A2 * 256, (int64_t)B2 * 256, bias0, bias1, bias2, x0, y0, x1, y1, zp, order);
-        }
+        const bool tiny = valid && fits32 && (bw * bh <= (n_wave >= kDenseWave ? kSmallAreaDense : kSmallArea));
+        if (tiny) sweep_small<int32_t, TILE>(vis, e0, e1, e2, sx0, sy0, sx1, sy1, sx2, sy2, bias0, bias1, bias2, x0, y0, x1, y1, zp, order);
         VR_PROF_MARK(2);
         bool rowp = false;
         // ---- small triangles, row by row (only when the wave holds enough of them to repay the hand-out; a few are
@@ -1277,8 +1359,6 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         // handed to the lanes 64 at a time; a lane fetches its row's triangle from the owning lane (ds_bpermute) and walks
         // the row's pixels.  Lane utilisation no longer depends on how many triangles the bin holds or how they are shaped.
         const bool row_ok = valid && !tiny && is_small;
-        // (offx, offy) in one word for the shuffles / broadcasts below: each fits 16 bits (|tile origin - anchor| < 16384)
-        const uint32_t offs = ((uint32_t)zp.offx & 0xffffu) | ((uint32_t)zp.offy << 16);
         if (__popcll(__ballot(row_ok)) >= kRowMin) {
             rowp = row_ok;
             const int rows = rowp ? bh : 0;
@@ -1288,9 +1368,9 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
             const int R = __builtin_amdgcn_readlane(incl, 63);
             if (R > 0) {        // (uniform: nothing below runs for a wave without row work)
                 // biased edge values at the box's first pixel; E_i - bias_i >= 0 <=> inside
-                const int32_t f0 = ((int32_t)e0 + __mul24(sy0, y0)) + (__mul24(sx0, x0) - bias0);
-                const int32_t f1 = ((int32_t)e1 + __mul24(sy1, y0)) + (__mul24(sx1, x0) - bias1);
-                const int32_t f2 = ((int32_t)e2 + __mul24(sy2, y0)) + (__mul24(sx2, x0) - bias2);
+                const int32_t f0 = (e0 + __mul24(sy0, y0)) + (__mul24(sx0, x0) - bias0);
+                const int32_t f1 = (e1 + __mul24(sy1, y0)) + (__mul24(sx1, x0) - bias1);
+                const int32_t f2 = (e2 + __mul24(sy2, y0)) + (__mul24(sx2, x0) - bias2);
                 const int start = incl - rows;
                 const uint32_t xb = (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16);
                 for (int cb = 0; cb < R; cb += 64) {
@@ -1323,36 +1403,16 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
             }
         }
         VR_PROF_MARK(3);
-        // big triangles (an edge longer than 64 pixels): broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its bbox
+        // everything else: broadcast one at a time (v_readlane -> SGPRs), all 64 lanes sweep its box
         unsigned long long big = __ballot(valid && !tiny && !rowp);
         VR_PROF_ADD(7, ((unsigned long long)__popcll(big) << 40) | ((unsigned long long)__popcll(__ballot(rowp)) << 20) | (unsigned long long)__popcll(__ballot(tiny)));
-        const uint32_t box = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
-        const uint32_t misc = (uint32_t)bias0 | ((uint32_t)bias1 << 1) | ((uint32_t)bias2 << 2) | (fits32 ? 8u : 0u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
 #define BC(v) __builtin_amdgcn_readlane((int)(v), src)
-#define BC64(v) (((int64_t)BC((int32_t)((v) >> 32)) << 32) | (int64_t)(uint32_t)BC((int32_t)(uint32_t)(v)))
-            const uint32_t m = (uint32_t)BC(misc), bx = (uint32_t)BC(box), ord = (uint32_t)BC(order), bo = (uint32_t)BC(offs);
-            ZPlane bz;
-            bz.z0 = __int_as_float(BC(__float_as_int(zp.z0))); bz.zx = __int_as_float(BC(__float_as_int(zp.zx)));
-            bz.zy = __int_as_float(BC(__float_as_int(zp.zy)));
-            bz.offx = (int)(int16_t)(bo & 0xffffu); bz.offy = (int)(int16_t)(bo >> 16);
-            const int b0 = m & 1u, b1 = (m >> 1) & 1u, b2 = (m >> 2) & 1u;
-            const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
-            if (m & 8u) {
-                if (max(qx1 - qx0, qy1 - qy0) + 1 >= min(kWalkMin, TILE - 4))
-                    sweep_walk<TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
-                                     BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
-                else
-                    sweep_big<int32_t, TILE>(vis, lane, BC((int32_t)e0), BC((int32_t)e1), BC((int32_t)e2), BC(sx0), BC(sy0),
-                                       BC(sx1), BC(sy1), BC(sx2), BC(sy2), b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
-            } else {
-                const int64_t a0 = BC(A0), bb0 = BC(B0), a1 = BC(A1), bb1 = BC(B1), a2 = BC(A2), bb2 = BC(B2);
-                sweep_big<int64_t, TILE>(vis, lane, BC64(e0), BC64(e1), BC64(e2), a0 * 256, bb0 * 256, a1 * 256, bb1 * 256, a2 * 256, bb2 * 256,
-                                   b0, b1, b2, qx0, qy0, qx1, qy1, bz, ord);
-            }
-#undef BC64
+            sweep_uniform(BC(e0), BC(e1), BC(e2), BC(sx0), BC(sy0), BC(sx1), BC(sy1), BC(sx2), BC(sy2), (uint32_t)BC(box),
+                          __int_as_float(BC(__float_as_int(zp.z0))), __int_as_float(BC(__float_as_int(zp.zx))), __int_as_float(BC(__float_as_int(zp.zy))),
+                          (uint32_t)BC(offs), (uint32_t)BC(order), (uint32_t)BC(flags));
 #undef BC
         }
         VR_PROF_MARK(4);
@@ -1664,7 +1724,8 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
                            g.d_tile_cursor, g.d_counters, a.bin_capacity, whole ? (const int32_t*)nullptr : (const int32_t*)pt->d_raster_tiles, n_scan,
                            g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
-    hipLaunchKernelGGL(k_fill, dim3(kGridFill), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, g.d_tile_cursor, g.d_bin_entries); }
+    hipLaunchKernelGGL(k_fill, dim3(kGridFill), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, (const uint4*)g.d_recs,
+                       (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_bin_entries); }
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
     g.geo_recorded = true;
     VR_HIP(hipGetLastError());

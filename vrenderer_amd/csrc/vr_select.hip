@@ -505,7 +505,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
 #define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
         vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } \
         t->bytes_scratch += (uint64_t)(bytes); } while (0)
-    t->bin_capacity = (size_t)16 << 20;
+    t->bin_capacity = (size_t)4 << 20;             // (triangle, tile) pairs per frame: an 8K frame has ~0.2 M, a 1080p frame ~0.6 M; beyond -> VR_ERR_OVERFLOW
     for (GeoSet& g : t->sets) {
         VR_ALLOC(g.d_node_ids, mi * sizeof(uint32_t));
         VR_ALLOC(g.d_instances, mi * sizeof(vr_instance));
@@ -517,7 +517,7 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
         VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
         VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
         VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
-        VR_ALLOC(g.d_bin_entries, t->bin_capacity * sizeof(uint32_t));
+        VR_ALLOC(g.d_bin_entries, t->bin_capacity * sizeof(TileEntry));
     }
 #undef VR_ALLOC
     for (GeoSet& g : t->sets) {
