@@ -11,7 +11,7 @@
 #if !defined(VR_EXPERIMENT_BUILD)
 #if defined(VR_EXP_FAST_SAMEADDR) || defined(VR_EXP_FAST_ALB1) || defined(VR_EXP_FAST_HGT1) || defined(VR_EXP_FAST_NOLEVEL1) || \
     defined(VR_EXP_TILED_STORES) || defined(VR_EXP_NOSTORE) || defined(VR_EXP_NOEMISSIVE) || defined(VR_EXP_NORECORD) || \
-    defined(VR_EXP_NOENCODE) || defined(VR_EXP_NOTABLES) || defined(VR_RASTER_PROFILE) || defined(VR_SELECT_PROFILE)
+    defined(VR_EXP_NOENCODE) || defined(VR_EXP_NOTABLES) || defined(VR_EXP_REC_ON_CHANGE) || defined(VR_EXP_REC_MASKED) || defined(VR_RASTER_PROFILE) || defined(VR_SELECT_PROFILE)
 #error "VR_EXP_* / VR_*_PROFILE switches produce wrong images or instrumented kernels: they need -DVR_EXPERIMENT_BUILD (tools/build_variant.py)"
 #endif
 #endif
@@ -66,6 +66,16 @@ constexpr bool kExpNoTables = true;
 #else
 constexpr bool kExpNoTables = false;
 #endif
+#ifdef VR_EXP_REC_ON_CHANGE      // the resolve's record fetch goes out of range (zeros, no memory access) for a lane whose next pixel has the same triangle
+constexpr bool kExpRecOnChange = true;
+#else
+constexpr bool kExpRecOnChange = false;
+#endif
+#ifdef VR_EXP_REC_MASKED         // ... or is not issued at all for such a lane (exec-masked fetch)
+constexpr bool kExpRecMasked = true;
+#else
+constexpr bool kExpRecMasked = false;
+#endif
 #ifdef VR_RASTER_PROFILE
 constexpr bool kExpRasterProfile = true;
 #else
@@ -79,7 +89,7 @@ constexpr bool kExpSelectProfile = false;
 
 constexpr unsigned kExpMask = (kExpSameAddr ? 1u : 0u) | (kExpOneAlbedo ? 2u : 0u) | (kExpOneHeight ? 4u : 0u) | (kExpNoLevel1 ? 8u : 0u)
                             | (kExpTiledStores ? 16u : 0u) | (kExpNoStore ? 32u : 0u) | (kExpNoEmissive ? 64u : 0u) | (kExpNoRecord ? 128u : 0u)
-                            | (kExpNoEncode ? 256u : 0u) | (kExpNoTables ? 512u : 0u) | (kExpRasterProfile ? 0x10000u : 0u) | (kExpSelectProfile ? 0x20000u : 0u)
+                            | (kExpNoEncode ? 256u : 0u) | (kExpNoTables ? 512u : 0u) | (kExpRecOnChange ? 1024u : 0u) | (kExpRecMasked ? 2048u : 0u) | (kExpRasterProfile ? 0x10000u : 0u) | (kExpSelectProfile ? 0x20000u : 0u)
 #ifdef VR_EXPERIMENT_BUILD
                             | 0x80000000u
 #endif

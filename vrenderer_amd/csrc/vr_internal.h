@@ -118,7 +118,8 @@ static_assert(sizeof(HardTriRec) == 32, "HardTriRec layout");
 // pixel (0, 0) and their steps per pixel, the triangle's pixel box inside the tile, the depth plane with the tile's origin
 // relative to the plane's anchor, and the draw-order word of the visibility buffer.  64 bytes = four 16-byte groups, so that
 // a sparse bin's entries can be read with scalar loads (the entry index is wave-uniform) straight into SGPRs: no per-lane
-// record fetch, no per-lane set-up, no v_readlane broadcast in the tile pass.
+// record fetch, no per-lane set-up, no v_readlane broadcast in the tile pass.  (With the resolve's planes in the
+// entry as well - 128 bytes - the tile pass alone gained 2.5 %, and k_fill, which runs beside it, cost the frame 2 %: not kept.)
 struct TileEntry {
     int32_t e0, e1, e2;                    // E_i at the tile's first pixel centre (bias NOT subtracted); exact when kTeFits32 is set
     int32_t sx0, sy0, sx1, sy1, sx2, sy2;  // steps per pixel: A_i * 256, B_i * 256
@@ -129,6 +130,8 @@ struct TileEntry {
     uint32_t flags;                        // bias0..2 (bits 0-2), kTeFits32, kTeValid, kTeSmall
 };
 static_assert(sizeof(TileEntry) == 64, "TileEntry layout");
+constexpr int kTeGroups = 4;                // 16-byte groups per entry
+constexpr int kTeSlotBits = 5;              // a bin of up to 32 entries keeps its triangles' planes in LDS: slot = low bits of the visibility word
 constexpr uint32_t kTeFits32 = 8u, kTeValid = 16u, kTeSmall = 32u;     // kTeSmall: every |A_i|, |B_i| <= 2^14 (the row hand-out's 24-bit products)
 
 // Screen-tile partition of a w x h frame for one rank of `world`: built once, immutable afterwards.

@@ -51,6 +51,11 @@ struct RasterArgs {
     int wireframe;                  // RasterFillMode::Wireframe: triangle edges as aliased lines
     float world_size, inv_world_size;
     int ws_pow2;                    // world_size is a power of two: x / ws == x * (1 / ws) exactly
+    // fast variant (power-of-two world size): what the implicit LOD multiplies the world-space derivatives by - texels per world
+    // unit, (float)w0 * inv_world_size: (d * inv_ws) * w0 == d * (inv_ws * w0) bit for bit, the scaling by a power of two commutes
+    // with the rounding (where d * inv_ws would be a denormal both forms give a LOD far below 0, clamped to 0) - and the last mip
+    // level as a float (the tile pass otherwise converts three integers per pixel: the compiler rematerialises them)
+    float lod_w, lod_h, max_level_f;
     uint32_t bin_capacity;
     uint32_t extra_vert_base, extra_vert_cap, hard_cap;
     float vp_x, vp_y, vp_w, vp_h;
@@ -782,6 +787,15 @@ __device__ __forceinline__ uint32_t snorm16_finite(float v)
     return (uint32_t)(int)(s + copysignf(0.5f, s)) & 0xffffu;      // == (s >= 0 ? s + 0.5 : s - 0.5) for every finite s
 }
 
+// A component of a NORMALISED vector (|v| <= 1 + a few ulps): v * 32767 rounds below 32767.5 without the clamp, so
+// (int)(s + copysign(0.5, s)) is vr_snorm16's result bit for bit; POSITIVE: the component is known to be > 0 (the normal's y).
+template <bool POSITIVE>
+__device__ __forceinline__ uint32_t snorm16_unit(float v)
+{
+    const float s = v * 32767.0f;
+    return (uint32_t)(int)(POSITIVE ? s + 0.5f : s + copysignf(0.5f, s)) & 0xffffu;
+}
+
 // One mip level of main_ps's five taps (terrain_ps.hlsl:59-61, :68): four height taps at uv +- 0.1 through the quad
 // table and the albedo footprint at uv.  SAME: heightmap and albedo have the same size (the reference's case), so the
 // albedo footprint is the floor / fraction pair the height taps at the unshifted u and v already computed.
@@ -941,6 +955,12 @@ struct FastTaps { u32x4 e0, e1, e2, e3, p00, p10, p01, p11; float fxa, fxb, fx0,
 #define FAST_AXIS(f_, i_, t_, n_, scale_) do { const float x_ = __builtin_fmaf((t_), (n_), -0.5f); const float xf_ = floorf(x_); (f_) = x_ - xf_; \
                                                 (i_) = (int)(vr_clampf(xf_, -1.0f, (n_)) * (scale_)); } while (0)
 
+// The same for the UNSHIFTED coordinates u, v of a pixel of the terrain: the interpolated world position lies inside its
+// triangle, i.e. on the terrain, so u, v are in [0, 1] to within rounding and floor(u * n - 0.5) in [-1, n - 1] - already inside
+// the clamp's range [-1, n] (it would take u < -0.5 / n or u >= 1 + 0.5 / n: 2e-4 beyond the terrain's edge on the finest level).
+#define FAST_AXIS_INSIDE(f_, i_, t_, n_, scale_) do { const float x_ = __builtin_fmaf((t_), (n_), -0.5f); const float xf_ = floorf(x_); (f_) = x_ - xf_; \
+                                                       (i_) = (int)(xf_ * (scale_)); } while (0)
+
 __device__ __forceinline__ FastTaps issue_level_fast(__amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc, const uint4* __restrict__ s_lv, int lvl16,
                                                      float ua, float ub, float va, float vb, float u0, float v0)
 {
@@ -948,8 +968,8 @@ __device__ __forceinline__ FastTaps issue_level_fast(__amdgpu_buffer_rsrc_t rq, 
     const uint4 L = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(s_lv) + lvl16);     // { offset of entry (1, 1), row bytes, (float)w, (float)h }
     const float wf = __uint_as_float(L.z), hf = __uint_as_float(L.w);
     int xa, xb, x0, y0, ya, yb;
-    FAST_AXIS(t.fxa, xa, ua, wf, 16.0f); FAST_AXIS(t.fxb, xb, ub, wf, 16.0f); FAST_AXIS(t.fx0, x0, u0, wf, 16.0f);
-    FAST_AXIS(t.fy0, y0, v0, hf, 1.0f); FAST_AXIS(t.fya, ya, va, hf, 1.0f); FAST_AXIS(t.fyb, yb, vb, hf, 1.0f);
+    FAST_AXIS(t.fxa, xa, ua, wf, 16.0f); FAST_AXIS(t.fxb, xb, ub, wf, 16.0f); FAST_AXIS_INSIDE(t.fx0, x0, u0, wf, 16.0f);
+    FAST_AXIS_INSIDE(t.fy0, y0, v0, hf, 1.0f); FAST_AXIS(t.fya, ya, va, hf, 1.0f); FAST_AXIS(t.fyb, yb, vb, hf, 1.0f);
     const uint32_t row0 = L.x + (uint32_t)__mul24(y0, (int)L.y), rowa = L.x + (uint32_t)__mul24(ya, (int)L.y), rowb = L.x + (uint32_t)__mul24(yb, (int)L.y);
     // (kExp*: timing experiments, all false in a product build - vr_experiments.h)
     const uint32_t am = kExpSameAddr ? 0xf0u : ~0u;
@@ -980,13 +1000,14 @@ __device__ __forceinline__ void filter_level_fast(const FastTaps& t, float hgt[4
     }
 }
 
-__device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f, float h0f, float max_level, __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc,
+__device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t rc,
                                                   const float* __restrict__ thr, const uint8_t* __restrict__ enc, const uint4* __restrict__ s_lv, const Attr& p,
                                                   uint32_t& diffuse, uint32_t& n01, uint32_t& n23 VR_PROF_PARAM)
 {
     const float half_ws = a.world_size * 0.5f, iws = a.inv_world_size;
     const float u = (p.wx + half_ws) * iws, v = (p.wz + half_ws) * iws;                       // :12-13, :20-21 (power-of-two world size)
-    const float lod = vr_lod_from_derivs_f(p.dwxdx * iws, p.dwzdx * iws, p.dwxdy * iws, p.dwzdy * iws, w0f, h0f);
+    const float max_level = a.max_level_f;
+    const float lod = vr_lod_from_derivs_f(p.dwxdx, p.dwzdx, p.dwxdy, p.dwzdy, a.lod_w, a.lod_h);     // (RasterArgs::lod_w: the division by the world size folded in)
     const float lc = vr_clampf(lod, 0.0f, max_level);            // == the sampler's clamp (vr_lod_split): lod is never NaN
     const float lf = floorf(lc), frac = lc - lf;
     const int l16 = (int)(lf * 16.0f);                           // the level as a byte offset into the LDS level table
@@ -1026,8 +1047,8 @@ __device__ __forceinline__ void pixel_shader_fast(const RasterArgs& a, float w0f
     else
     diffuse = srgb_encode_nonneg(col[0], thr, enc) | (srgb_encode_nonneg(col[1], thr, enc) << 8) | (srgb_encode_nonneg(col[2], thr, enc) << 16)
             | 0xff000000u;                                                                  // :68, :73-75
-    n01 = snorm16_finite(nx) | (snorm16_finite(ny) << 16);                                  // :78
-    n23 = snorm16_finite(nz) | (32767u << 16);                                              // :79 roughness = 1
+    n01 = snorm16_unit<false>(nx) | (snorm16_unit<true>(ny) << 16);                         // :78
+    n23 = snorm16_unit<false>(nz) | (32767u << 16);                                         // :79 roughness = 1
     VR_PROF_MARK(14);
 }
 
@@ -1044,9 +1065,10 @@ constexpr int kDenseWave = 32, kSmallAreaDense = 128;   // ... <= 128 pixels whe
 #endif
 constexpr int kRowMin = VR_ROW_MIN;  // the row hand-out needs this many eligible triangles in a wave (its scan + fetches are a fixed cost)
 #ifndef VR_SPARSE_MAX
-#define VR_SPARSE_MAX 48
+#define VR_SPARSE_MAX 32
 #endif
-constexpr int kSparseMax = VR_SPARSE_MAX;   // bins up to this long are walked entry by entry with scalar loads (k_raster's coverage)
+constexpr int kSparseMax = VR_SPARSE_MAX;   // bins up to this long are walked entry by entry with scalar loads (k_raster's coverage) and keep their planes in LDS
+static_assert(kSparseMax <= (1 << kTeSlotBits), "an entry's slot must fit the visibility word's low bits");
 constexpr int kSweepW = 8;          // cooperative sweep block: 8 x 8 pixels (4x16, 16x4, 32x2, 64x1 measured 2-20 % slower)
 
 // The depth plane of a triangle as the coverage sweeps carry it: coefficients + the tile's origin relative to the anchor
@@ -1219,6 +1241,10 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     __shared__ float thr[kThrTabSize];
     __shared__ uint32_t s_qoff[kMaxLevels], s_aoff[kMaxLevels];
     __shared__ uint4 s_lv[kMaxLevels];                 // fast variant: DevTex::fast_lv (the same for both textures)
+    // The interpolation planes of a sparse bin's triangles (record groups 5-7), 48 B per entry: the resolve reads a pixel's winner
+    // from here by the slot in its visibility word - three LDS reads instead of three fetches per pixel and lane (tile pass alone
+    // -2.5 %; profiles/r04_tile_pass_experiments.txt).  Ninety-six lanes fetch them while the sweeps run.
+    __shared__ uint4 s_rec[MODE != RM_DEPTH ? 3 * (1 << kTeSlotBits) : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
@@ -1239,6 +1265,12 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     const uint32_t off = tile_offset[tile], n_all = tile_cursor[tile] - off;     // bin = entries[off .. off + n_all)
     const uint32_t n = min(n_all, off < a.bin_capacity ? a.bin_capacity - off : 0u);   // (an overflowing frame drops the entries beyond the capacity: VR_ERR_OVERFLOW)
     const TileEntry* __restrict__ bin = entries + off;
+    const bool lds_recs = !WIRE && MODE != RM_DEPTH && n <= (uint32_t)kSparseMax;      // (workgroup-uniform)
+    uint4 rec_r = make_uint4(0, 0, 0, 0);                         // requested now, stored behind the sweeps: its latency is theirs
+    if (lds_recs && (uint32_t)tid < n * 3u) {
+        const uint32_t ord_j = bin[(uint32_t)tid / 3u].order;     // entry -> key -> record (two dependent fetches, under the buffer's set-up and the sweeps)
+        rec_r = recs[rec_index(key_of(ord_j), hard_first, rec_hard_base) * kRecGroups + 5u + (uint32_t)tid % 3u];
+    }
     // consecutive bin entries go to different waves so that a short list still uses all of them
     const uint32_t idx0 = (uint32_t)(lane * kRW + wave);
     const int tyi = tile / a.rtx, txi = tile - tyi * a.rtx;
@@ -1274,8 +1306,8 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     // from the triangle's record - five 16-byte fetches behind the key's, ~250 vector instructions per wave whether the wave held
     // two entries or sixty - and broadcast each swept triangle with ~25 v_readlane.
     // A wide triangle (edge values beyond 31 bits over the tile: kTeFits32 clear; rare) is redone in 64 bits from its record.
-    auto sweep_wide = [&](uint32_t ord, uint32_t bx, uint32_t flags, const ZPlane& zz) {          // (wave-uniform arguments)
-        const uint32_t key = key_of(ord);
+    auto sweep_wide = [&](uint32_t ord, uint32_t key_ord, uint32_t bx, uint32_t flags, const ZPlane& zz) {          // (wave-uniform arguments)
+        const uint32_t key = key_of(key_ord);
         const uint4* __restrict__ rp = recs + rec_index(key, hard_first, rec_hard_base) * kRecGroups;
         const uint4 g0 = rp[0], g1 = rp[1], g2 = rp[2];
         const int64_t e0 = edge_eval((int32_t)g0.x, (int32_t)g0.y, rec_c(g0), PX0, PY0), e1 = edge_eval((int32_t)g1.x, (int32_t)g1.y, rec_c(g1), PX0, PY0),
@@ -1286,11 +1318,11 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     };
     // One (wave-uniform) entry swept by all 64 lanes: along its long axis when that is most of a tile, else in 8x8 blocks.
     auto sweep_uniform = [&](int32_t e0, int32_t e1, int32_t e2, int32_t sx0, int32_t sy0, int32_t sx1, int32_t sy1, int32_t sx2, int32_t sy2,
-                             uint32_t bx, float z0, float zx, float zy, uint32_t bo, uint32_t ord, uint32_t flags) {
+                             uint32_t bx, float z0, float zx, float zy, uint32_t bo, uint32_t ord, uint32_t flags, uint32_t key_ord) {
         ZPlane bz;
         bz.z0 = z0; bz.zx = zx; bz.zy = zy;
         bz.offx = (int)(int16_t)(bo & 0xffffu); bz.offy = (int)(int16_t)(bo >> 16);
-        if (!(flags & kTeFits32)) { sweep_wide(ord, bx, flags, bz); return; }
+        if (!(flags & kTeFits32)) { sweep_wide(ord, key_ord, bx, flags, bz); return; }
         const int b0 = flags & 1u, b1 = (flags >> 1) & 1u, b2 = (flags >> 2) & 1u;
         const int qx0 = bx & 255u, qy0 = (bx >> 8) & 255u, qx1 = (bx >> 16) & 255u, qy1 = bx >> 24;
         if (max(qx1 - qx0, qy1 - qy0) + 1 >= min(kWalkMin, TILE - 4))
@@ -1305,14 +1337,15 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
         const uint4* __restrict__ q = reinterpret_cast<const uint4*>(bin);
         uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-        if (w0 < n) { n0 = q[w0 * 4 + 0]; n1 = q[w0 * 4 + 1]; n2 = q[w0 * 4 + 2]; n3 = q[w0 * 4 + 3]; }
+        if (w0 < n) { n0 = q[w0 * kTeGroups + 0]; n1 = q[w0 * kTeGroups + 1]; n2 = q[w0 * kTeGroups + 2]; n3 = q[w0 * kTeGroups + 3]; }
         for (uint32_t j = w0; j < n; j += kRW) {
             const uint4 t0 = n0, t1 = n1, t2 = n2, t3 = n3;
             const uint32_t jn = j + kRW;
-            if (jn < n) { n0 = q[jn * 4 + 0]; n1 = q[jn * 4 + 1]; n2 = q[jn * 4 + 2]; n3 = q[jn * 4 + 3]; }
+            if (jn < n) { n0 = q[jn * kTeGroups + 0]; n1 = q[jn * kTeGroups + 1]; n2 = q[jn * kTeGroups + 2]; n3 = q[jn * kTeGroups + 3]; }
             if (!(t3.w & kTeValid)) continue;
+            // the visibility word of a sparse bin: draw order (27 bits, later = smaller, as ever) above the entry's slot
             sweep_uniform((int32_t)t0.x, (int32_t)t0.y, (int32_t)t0.z, (int32_t)t0.w, (int32_t)t1.x, (int32_t)t1.y, (int32_t)t1.z, (int32_t)t1.w, (int32_t)t2.x,
-                          t2.y, __uint_as_float(t2.z), __uint_as_float(t2.w), __uint_as_float(t3.x), t3.y, t3.z, t3.w);
+                          t2.y, __uint_as_float(t2.z), __uint_as_float(t2.w), __uint_as_float(t3.x), t3.y, MODE != RM_DEPTH ? (t3.z << kTeSlotBits) | j : t3.z, t3.w, t3.z);
         }
         VR_PROF_MARK(4);
     } else
@@ -1412,11 +1445,12 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
 #define BC(v) __builtin_amdgcn_readlane((int)(v), src)
             sweep_uniform(BC(e0), BC(e1), BC(e2), BC(sx0), BC(sy0), BC(sx1), BC(sy1), BC(sx2), BC(sy2), (uint32_t)BC(box),
                           __int_as_float(BC(__float_as_int(zp.z0))), __int_as_float(BC(__float_as_int(zp.zx))), __int_as_float(BC(__float_as_int(zp.zy))),
-                          (uint32_t)BC(offs), (uint32_t)BC(order), (uint32_t)BC(flags));
+                          (uint32_t)BC(offs), (uint32_t)BC(order), (uint32_t)BC(flags), (uint32_t)BC(order));
 #undef BC
         }
         VR_PROF_MARK(4);
     }
+    if (lds_recs && (uint32_t)tid < n * 3u) s_rec[tid] = rec_r;
     __syncthreads();
     VR_PROF_MARK(5);
 
@@ -1427,7 +1461,6 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                                            : __builtin_amdgcn_make_buffer_rsrc((void*)hm.quadf, (short)0, (int)(hm.quad_bytes * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = FAST ? __builtin_amdgcn_make_buffer_rsrc((void*)al.fast, (short)0, (int)al.fast_bytes, 0x00020000)
                                            : __builtin_amdgcn_make_buffer_rsrc((void*)al.rgbf, (short)0, (int)(al.chain_bytes * 4u), 0x00020000);
-    const float w0f = (float)hm.w0, h0f = (float)hm.h0, max_level = (float)(hm.levels - 1);
     // targets through one buffer resource when the planes lie within 4 GB of the depth plane (a vr_gbuffer of up to 16K x 8K;
     // the host launches the fast variant only then)
     const uint64_t gb_span = (uint64_t)(reinterpret_cast<const char*>(g_emi + (size_t)a.w * a.h) - reinterpret_cast<const char*>(g_depth));
@@ -1475,6 +1508,12 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     typedef unsigned int u3 __attribute__((ext_vector_type(3)));
     struct Rec { u32x4 g5; u3 g6, g7; };
     auto fetch_rec = [&](uint32_t low) -> Rec {
+        if (lds_recs) {                                          // (workgroup-uniform) a sparse bin: the winner's planes by its slot
+            const char* e = reinterpret_cast<const char*>(s_rec) + (low & (uint32_t)((1 << kTeSlotBits) - 1)) * 48u;
+            Rec r;
+            r.g5 = *reinterpret_cast<const u32x4*>(e); r.g6 = *reinterpret_cast<const u3*>(e + 16); r.g7 = *reinterpret_cast<const u3*>(e + 32);
+            return r;
+        }
         const uint32_t key = key_of(low);
         uint32_t idx = key >> 4;
         const bool hard = (key & 1u) != 0u && low != 0xffffffffu;
@@ -1484,6 +1523,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
         const uint32_t off = idx << 7;                           // an uncovered pixel: 0x0fffffff << 7 = far beyond rec_bytes -> zeros
         Rec r;
         if (kExpNoRecord) { r.g5 = (u32x4){ 0x3f800000u, 0u, 0u, 0u }; r.g6 = (u3){ off, 0x3a800000u, 0u }; r.g7 = (u3){ 0x3f000000u, 0u, 0x3a800000u }; return r; }
+
         r.g5 = __builtin_amdgcn_raw_buffer_load_b128(rrec, off, 80, 0);
         r.g6 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 96, 0);
         r.g7 = __builtin_amdgcn_raw_buffer_load_b96(rrec, off, 112, 0);
@@ -1524,7 +1564,12 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
             const unsigned long long key = keys[k];
             const uint32_t low = (uint32_t)key;
             const u32x4 g5 = nrec.g5; const u3 g6 = nrec.g6, g7 = nrec.g7;    // this pixel's record (requested one pixel ago)
-            if (!depth_only) nrec = fetch_rec((uint32_t)(k < 3 ? keys[k + 1] : nkeys[0]));
+            if (!depth_only) {
+                const uint32_t nlow = (uint32_t)(k < 3 ? keys[k + 1] : nkeys[0]);
+                if (kExpRecOnChange) nrec = fetch_rec(nlow != low ? nlow : 0xffffffffu);             // (timing experiments: wrong image)
+                else if (kExpRecMasked) { if (nlow != low) nrec = fetch_rec(nlow); }
+                else nrec = fetch_rec(nlow);
+            }
             if (!inside || (!whole && gy0 + k >= a.h)) continue;
             const bool cov = low != 0xffffffffu;
             if (!cov && !a.assume_cleared) continue;               // keep what the target holds
@@ -1557,7 +1602,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                     p.dwxdy = __builtin_fmaf(-p.wx, qy, nxy) * r; p.dwzdy = __builtin_fmaf(-p.wz, qy, nzy) * r;
                 }
                 VR_PROF_MARK(9);
-                if (FAST) pixel_shader_fast(a, w0f, h0f, max_level, rq, rc, thr, enc, s_lv, p, dif, nn0, nn1 VR_PROF_ARG);
+                if (FAST) pixel_shader_fast(a, rq, rc, thr, enc, s_lv, p, dif, nn0, nn1 VR_PROF_ARG);
                 else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
             if (kExpNoStore) {        // (a dependent dummy keeps the shading alive)
@@ -1639,6 +1684,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     a.depth_only = rp->depth_only; a.assume_cleared = rp->assume_cleared; a.wireframe = rp->wireframe ? 1 : 0;
     a.world_size = t->p.world_size; a.inv_world_size = 1.0f / t->p.world_size;
     { uint32_t wb; memcpy(&wb, &t->p.world_size, 4); a.ws_pow2 = (wb & 0x7fffffu) == 0u && t->p.world_size >= 1.0f && t->p.world_size <= 65536.0f; }
+    a.lod_w = (float)t->height.w0 * a.inv_world_size; a.lod_h = (float)t->height.h0 * a.inv_world_size; a.max_level_f = (float)(t->height.levels - 1);
     a.bin_capacity = (uint32_t)t->bin_capacity;
     a.extra_vert_base = (uint32_t)t->p.max_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
     a.vp_x = (float)view->viewport_x; a.vp_y = (float)view->viewport_y; a.vp_w = (float)view->viewport_w; a.vp_h = (float)view->viewport_h;
