@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--no-submit", action="store_true",
                     help="queue a frame through the per-call entry points (Render, Prepare x 2, Light, tone-map stage: ~9 calls) instead of "
                          "vr_frame_submit (one call); A/B of the host's cost per frame")
+    ap.add_argument("--fused", action="store_true",
+                    help="opt-in fused variant (vr_terrain_render_lit, SURVEY 7 step 6): the tile pass shades what it rasterises and writes depth + "
+                         "HdrColor only - same bits as the two passes; reported as the `fused` sub-record of the default run, never as the headline")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second timed region (the same K frames after one more lap of load)")
     ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
                     help="vr_timing_enable level inside the timed region: 2 = dispatch-stamped events on the two big kernels (default), "
@@ -403,7 +406,9 @@ def main():
 
     # one call per frame (vr_frame_submit: Render [+ Clear] -> Prepare x 2 -> lighting [-> tone-map stage]); the shadow path keeps
     # the per-call sequence (its shadow-map pass sits between frames)
-    use_submit = not args.no_submit and shadow_map is None and not args.no_prepare
+    if args.fused and (tiled or shadow_map is not None or use_dist):
+        raise SystemExit("--fused: the fused kernel takes the streaming pass's plain case (<= 16 lights, no shadow term) on one GPU or an emulated rank")
+    use_submit = not args.no_submit and shadow_map is None and not args.no_prepare and not args.fused
     frame_call = None
     if use_submit:
         stage = dict(tonemap=tm, tonemap_params=tmp, ldr=ldr_img) if (emu and emu_ldr) else {}
@@ -425,14 +430,18 @@ def main():
             out_img = emu_hdr[i % 2] if emu else hdr
             if emu and emu_ldr:
                 main_stream.wait_event(emu_tm_done[i % 2])         # the packed tiles of two frames ago have been consumed
-            tp.Render(v, v, rt, rp, part)
+            if args.fused:
+                tp.RenderLit(v, rt, rp, lights, AMBIENT_TOP, AMBIENT_BOTTOM, out_img, part)
+            else:
+                tp.Render(v, v, rt, rp, part)
             if not args.no_prepare:
                 if shadow_map is None:
                     prepare_ahead(i, part)
                 else:                                # both passes of frame i+1: its shadow map's geometry, then its main view's
                     shadow_map.PrepareTerrain(tp, lights[0], views[(i + 1) % 120])
                     tp.Prepare(views[(i + 1) % 120], rt, rp, part)
-            light(v, out_img, part)
+            if not args.fused:
+                light(v, out_img, part)
             if emu and emu_ldr:
                 emu_render_done[i % 2].record(main_stream)
                 with torch.cuda.stream(comm_stream):
@@ -616,7 +625,7 @@ def main():
         last = views[idx % 120]
         got = frame.download()
         ref_img = vr.HdrImage(ctx, W, H)
-        tp.Render(last, last, rt, rp, None)
+        tp.Render(last, last, rt, rp, None)                 # (the comparison frame is always the unfused pair)
         if shadow_map is not None:
             shadow_map.SetupForPlanarViewStable(lights[0], last)
             shadow_map.RenderTerrain(tp)
@@ -847,6 +856,32 @@ def main():
                                       "note": "not bandwidth-bound (SURVEY 7): 1.6 lights reach a covered pixel on average, ~85 instructions each"}
             except Exception as e:
                 out["lights_1024"] = {"error": repr(e)}
+        if args.fused:
+            out["config"]["workload"] += "; FUSED variant (vr_terrain_render_lit): lighting inside the tile pass, depth + HdrColor written (12 B/px)"
+            out["roofline"] = None
+            out["roofline_gbuffer_fill"] = None
+            fk = "k_raster (fused with lighting)"
+            if fk in timings:
+                ms_f, n_f = timings[fk]
+                out["roofline_fused"] = {"kernel": fk, "bound": "hbm", "bytes_per_pixel": 12, "achieved": round(12 * owned_px / (ms_f / n_f * 1e-3) / 1e9, 1),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(12 * owned_px / (ms_f / n_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "avg_us": round(ms_f / n_f * 1e3, 2),
+                                         "note": "depth 4 B + HdrColor 8 B written per pixel, nothing read back; bound by the tile pass's own work, not by HBM"}
+        if world == 1 and not use_dist and not emu and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows and not tiled and not args.fused:
+            # the opt-in fused variant on the same workload (child process): reported beside the graded path, never instead of it
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--no-cpu-baseline", "--no-4k", "--verify"] + (["--fixed-camera"] if args.fixed_camera else []),
+                                   capture_output=True, text=True, timeout=300)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["fused"] = {"what": "vr_terrain_render_lit (opt-in, SURVEY 7 step 6): TerrainPass::Render + DeferredLightingPass::Render in one pass over the pixels; "
+                                        "HdrColor and depth bit-identical to the two passes (frame_verified_against_unfused), the other G-buffer planes not written",
+                                "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "sustained": j.get("sustained"),
+                                "roofline_fused": j.get("roofline_fused"), "frame_verified_against_unfused": j.get("frame_verified_against_unsplit"),
+                                "kernels": {k: v["avg_us"] for k, v in j["kernels"].items() if k.startswith("k_raster")}}
+            except Exception as e:
+                out["fused"] = {"error": repr(e)}
         if world == 1 and not emu and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(size, hm, al, params, (AMBIENT_TOP, AMBIENT_BOTTOM), camera)

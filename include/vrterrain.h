@@ -178,7 +178,10 @@ VR_API uint32_t vr_build_experiments(void);
  * Renderer.cpp:326-437).  Kernel ids: */
 enum { VR_K_SELECT = 0, VR_K_VERTEX, VR_K_SETUP, VR_K_CLIP, VR_K_SCAN, VR_K_FILL, VR_K_RASTER,
        VR_K_DEFERRED, VR_K_DETILE, VR_K_CLEAR, VR_K_DEFERRED_TILED, VR_K_NODE_HEIGHTS,
-       VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_RASTER_DEPTH, VR_K_LIGHT_CULL, VR_K_COUNT };
+       VR_K_TM_HISTOGRAM, VR_K_TM_EXPOSURE, VR_K_TONEMAP, VR_K_DETILE_LDR, VR_K_RASTER_DEPTH, VR_K_LIGHT_CULL, VR_K_RASTER_LIT, VR_K_COUNT };
+/* (VR_K_COUNT grows when kernels are added - 16 in round 2, 18 in round 3, 19 now: size vr_timing_collect's arrays with the
+ * constant of the header the host is compiled against AND check vr_timing_kernel_count() at run time) */
+VR_API int  vr_timing_kernel_count(void);
 VR_API int  vr_timing_enable(vr_context* ctx, int enable);     /* also resets the samples; 1 = every kernel (two event records per
                                                                 * launch), 2 = only the tile pass and the lighting passes, whose
                                                                 * events the dispatch stamps at no host cost */
@@ -242,6 +245,17 @@ VR_API int  vr_terrain_select(vr_terrain* t, const vr_view* view, float max_heig
 VR_API int  vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev,
                               vr_gbuffer* gb, const vr_render_params* rp,
                               const vr_partition* part);
+/* Opt-in fused variant: TerrainPass::Render + DeferredLightingPass::Render in ONE pass over the pixels.  The tile
+ * pass's resolve encodes each pixel to the G-buffer's formats in registers, decodes and shades it with the lighting pass's own
+ * arithmetic and writes depth + hdr_out only (the other four G-buffer planes keep what they held): 12 bytes per pixel reach memory
+ * instead of 28 + 36.  depth and hdr_out (HdrColor, or this rank's packed RGB16F tiles with a partition) are bit-identical to
+ * vr_terrain_render(assume_cleared = 1) + vr_deferred_light on the same inputs.  Needs render->assume_cleared = 1, shaded fill
+ * mode, <= 16 lights.  The fused kernel covers the reference's case (heightmap and albedo of one size, power-of-two world size,
+ * directional / punctual point lights, no shadow term); for anything else the call runs the two passes one after the other.
+ * vr_terrain_prepare works as for vr_terrain_render.  The unfused pair stays the default path (and the measured one). */
+VR_API int  vr_terrain_render_lit(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp,
+                                  const vr_partition* part, const vr_light* lights, int32_t num_lights,
+                                  const float ambient_top[3], const float ambient_bottom[3], vr_image* hdr_out);
 /* Optional: build the view-dependent geometry (select .. bins) of an upcoming vr_terrain_render ahead of
  * time, on one of the terrain's two geometry streams.  Called right after vr_terrain_render of frame N with frame
  * N+1's view, it overlaps frame N's tile pass (and leaves its lighting pass alone).  Up to two frames may be prepared

@@ -1305,6 +1305,82 @@ def test_frame_submit_equals_the_per_call_sequence(scene256, oracle, gpu_ctx, cr
             tctx.close()
 
 
+def _fused_vs_unfused(tp, gpu_ctx, v, w, h, lights, part=None):
+    from vrenderer_amd.passes import partition_info
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    if part is None:
+        mk = lambda: vr.HdrImage(gpu_ctx, w, h)
+        nbytes = None
+    else:
+        info = partition_info(w, h, part.rank, part.world_size)
+        rows = (info["packed_bytes"] + vr.VR_OWNER_TILE * 8 - 1) // (vr.VR_OWNER_TILE * 8)
+        mk = lambda: vr.HdrImage(gpu_ctx, vr.VR_OWNER_TILE, rows)
+        nbytes = info["owned"] * 128 * 128 * 6            # the live tiles of the packed buffer
+    a, b = mk(), mk()
+    for img in (a, b):                                     # (pixels of a partial edge tile that lie outside the frame are never written)
+        img.upload(np.zeros(img.width * img.height * 4, np.uint16))
+    tp.Render(v, v, rt, rp, part)
+    vr.DeferredLightingPass(gpu_ctx).Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, a, part)
+    depth_a = rt.download("depth").copy()
+    want = a.download(nbytes).copy()
+    rt.Clear()                                             # (the fused pass must not depend on what the other planes hold)
+    tp.RenderLit(v, rt, rp, lights, AMBIENT_TOP, AMBIENT_BOTTOM, b, part)
+    got = b.download(nbytes)
+    depth_b = rt.download("depth")
+    for o in (a, b, rt):
+        o.close()
+    return want, got, depth_a, depth_b
+
+
+def test_fused_render_lit_equals_render_plus_lighting(scene256, scene2048, oracle, gpu_ctx):
+    """vr_terrain_render_lit (opt-in): the tile pass's resolve shades what it has just encoded and writes depth +
+    HdrColor only.  Bit-identical to vr_terrain_render + vr_deferred_light - sun only, sun + point lights (the exact-position
+    branch), whole frames and the packed tiles of a 3-way split, both raster tile sizes - and within the stated 1e-4 RMS of the
+    oracle like the unfused pair; spot lights fall back to the two passes inside the call."""
+    sun = [vr.reference_sun()]
+    lamps = sun + [vr.point_light((10.0, 40.0, -5.0), 3000.0, 120.0, (1.0, 0.5, 0.25)), vr.point_light((-30.0, 35.0, 30.0), 2000.0, 150.0, (0.9, 0.9, 1.0))]
+    spots = sun + [vr.spot_light((-20.0, 60.0, 10.0), (0.3, -1.0, -0.2), 6000.0, 200.0, 12.0, 25.0, (0.2, 1.0, 0.4))]
+    cases = [(scene256, 256, 512, 288, CAMERAS[0], sun, None), (scene256, 256, 512, 288, CAMERAS[5], lamps, None),
+             (scene256, 256, 640, 360, CAMERAS[1], lamps, vr.Partition(1, 3)), (scene2048, 2048, 1920, 1080, CAMERAS[0], sun, None),
+             (scene2048, 2048, 1920, 1080, CAMERAS[3], lamps, vr.Partition(5, 8)), (scene256, 256, 512, 288, CAMERAS[0], spots, None)]
+    for tile in (0, 64):
+        gpu_ctx.set_raster_tile(tile)
+        try:
+            for sc, size, w, h, cam, lights, part in cases:
+                v = vr.make_view(*scaled_camera(cam, size), w, h)
+                want, got, da, db = _fused_vs_unfused(sc["tp"], gpu_ctx, v, w, h, lights, part)
+                what = f"{w}x{h} scene {size} lights {len(lights)} part {None if part is None else (part.rank, part.world_size)} tile {tile}"
+                assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "depth: " + what
+                assert np.array_equal(want, got), f"HdrColor differs at {(want != got).sum()} halfs: " + what
+        finally:
+            gpu_ctx.set_raster_tile(0)
+    # ... and against the oracle (one case; the unfused pair has its own tests)
+    w, h = 512, 288
+    v = vr.make_view(*scaled_camera(CAMERAS[0], 256), w, h)
+    _, got, _, _ = _fused_vs_unfused(scene256["tp"], gpu_ctx, v, w, h, sun)
+    gb = oracle.GBufferHost(w, h)
+    scene256["ot"].render(v, gb, vr.default_render_params(400.0))
+    ref = oracle.deferred(v, gb, sun, AMBIENT_TOP, AMBIENT_BOTTOM)
+    d = oracle.half_to_float(got).astype(np.float64) - oracle.half_to_float(ref).astype(np.float64)
+    assert np.sqrt(np.mean(d ** 2)) <= 1e-4
+
+
+def test_fused_render_lit_at_8k_and_split_eight_ways(scene2048, gpu_ctx):
+    """The fused variant at BASELINE's size: the whole 7680x4320 frame and all eight ranks' packed tiles equal the unfused pair
+    byte for byte (a size-independent property: both sides are the HIP path)."""
+    from vrenderer_amd.passes import frame_detile
+    w, h = 7680, 4320
+    v = vr.make_view(*CAMERAS[1], w, h)
+    sun = [vr.reference_sun()]
+    want, got, da, db = _fused_vs_unfused(scene2048["tp"], gpu_ctx, v, w, h, sun)
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32)) and np.array_equal(want, got)
+    assert (da < 1.0).mean() > 0.3
+    for r in range(8):
+        wp, gp, _, _ = _fused_vs_unfused(scene2048["tp"], gpu_ctx, v, w, h, sun, vr.Partition(r, 8))
+        assert np.array_equal(wp, gp), f"rank {r} of 8"
+
+
 def _render_view_both(sc, oracle, gpu_ctx, v, w, h, **rpkw):
     ot, tp = sc["ot"], sc["tp"]
     rp = vr.default_render_params(400.0, **rpkw)

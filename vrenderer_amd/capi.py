@@ -20,7 +20,7 @@ VR_ERR_HIP = 6
 VR_LIGHT_DIRECTIONAL = 1
 VR_LIGHT_SPOT = 2
 VR_LIGHT_POINT = 3
-VR_K_COUNT = 18
+VR_K_COUNT = 19
 VR_TONEMAP_BINS = 256
 VR_OPT_ASYNC_GEOMETRY = 1
 VR_OPT_DISPATCH_EVENTS = 2
@@ -143,9 +143,9 @@ if os.environ.get("VRTERRAIN_LIB"):          # development: A/B another build of
 # every symbol include/vrterrain.h declares
 EXPORTS = [
     "vr_context_create", "vr_context_destroy", "vr_context_set_stream", "vr_context_set_option", "vr_context_synchronize",
-    "vr_last_error", "vr_version", "vr_build_experiments", "vr_timing_enable", "vr_timing_collect", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
+    "vr_last_error", "vr_version", "vr_build_experiments", "vr_timing_enable", "vr_timing_collect", "vr_timing_kernel_count", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
-    "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_prepare", "vr_terrain_num_chunks",
+    "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_render_lit", "vr_terrain_prepare", "vr_terrain_num_chunks",
     "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe", "vr_gbuffer_plane_known_zero",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_ldr_image_create", "vr_ldr_image_destroy", "vr_ldr_image_device_ptr", "vr_ldr_image_capacity", "vr_ldr_image_download", "vr_ldr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_deferred_tiled_status", "vr_partition_num_tiles",
@@ -240,6 +240,8 @@ def load_library():
         "vr_frame_allgather_ldr": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
         "vr_frame_allgather_tiles": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_size_t]),
         "vr_frame_submit": (C.c_int, [vp, vp, P(FrameDesc)]),
+        "vr_timing_kernel_count": (C.c_int, []),
+        "vr_terrain_render_lit": (C.c_int, [vp, P(View), vp, P(RenderParams), P(Partition), P(Light), C.c_int32, P(C.c_float), P(C.c_float), vp]),
         "vr_tonemap_allreduce_histogram": (C.c_int, [vp, vp]),
         "vr_shadow_default_params": (None, [P(ShadowParams), C.c_float]),
         "vr_shadow_view_setup": (C.c_int, [P(Light), P(View), P(ShadowParams), P(View)]),

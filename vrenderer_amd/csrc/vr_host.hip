@@ -221,11 +221,13 @@ extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT],
     timing_reset(c);                                     // also on the error path: a bad pair must not persist
     return rc;
 }
+extern "C" VR_API int vr_timing_kernel_count(void) { return VR_K_COUNT; }
 extern "C" VR_API const char* vr_kernel_name(int id)
 {
     static const char* names[VR_K_COUNT] = { "k_select", "k_vertex", "k_setup", "k_clip", "k_scan", "k_fill", "k_raster",
                                               "k_deferred", "k_detile", "k_fill_u32 (clear)", "k_deferred_tiled", "k_node_heights (all levels)",
-                                              "k_tm_histogram", "k_tm_exposure", "k_tonemap", "k_detile_ldr", "k_raster (depth only)", "k_light_cull" };
+                                              "k_tm_histogram", "k_tm_exposure", "k_tonemap", "k_detile_ldr", "k_raster (depth only)", "k_light_cull",
+                                              "k_raster (fused with lighting)" };
     return (id >= 0 && id < VR_K_COUNT) ? names[id] : "?";
 }
 

@@ -26,7 +26,9 @@
 // bit-identical to the CPU oracle.
 #include "vr_internal.h"
 #include "vr_tex_dev.h"
+#include "vr_deferred_dev.h"
 #include "vr_experiments.h"
+#include <type_traits>
 
 #include <stdlib.h>
 #include <string.h>
@@ -1217,14 +1219,26 @@ enum { RM_GENERIC = 0, RM_FAST = 1, RM_DEPTH = 2 };
 // RANGES (fast variant only): the depth range of every 32x32 light tile is left at `ranges` for the tiled lighting pass.
 // NOEMI (fast variant only): the emissive plane is known to hold zeros already (vr_gbuffer::emissive_zero) and is not rewritten -
 // main_ps's o_channel3 = 0 (terrain_ps.hlsl:80) changes nothing there; 8 of the 28 bytes a pixel sends through the CU's store path.
-template <bool WIRE, int TILE, int MODE, bool RANGES = false, bool NOEMI = false>
+// LIT (fast variant only; vr_terrain_render_lit): the fused pass of SURVEY 7 step 6 - the resolve encodes the pixel to the
+// G-buffer's formats in registers, decodes and shades it with the lighting pass's own arithmetic (shade_pixel, vr_deferred_dev.h)
+// and stores depth + HdrColor only: 12 bytes per pixel leave the pass instead of 28, and the lighting pass's 36 are not moved at
+// all.  Same bits as vr_terrain_render + vr_deferred_light.  Opt-in; the unfused pair stays the default and the graded path.
+struct LitArgs {
+    DeferredArgs da;                   // the lighting pass's constants
+    const float* lut_g;                // sRGB8 -> linear (256 floats)
+    uint2* hdr;                        // HdrColor, row-major RGBA16F - or, with a partition, this rank's packed RGB16F tiles
+    const int32_t* tile_slot;          // partition: owner tile -> rank * max_owned + local index (NULL: whole frame, row-major)
+    int slot_base, owner_tiles_x;
+};
+struct LitNone { int unused; };
+template <bool WIRE, int TILE, int MODE, bool RANGES = false, bool NOEMI = false, bool LIT = false>
 // A 32-pixel tile's workgroup needs 11 KB of LDS: registers, not LDS, decide how many fit a CU.  Asked for six waves per SIMD
 // the compiler fits every 32-pixel variant into 80 VGPRs without a spill (84-90 otherwise: five waves): 5120x2880 frame
 // 0.288 -> 0.279 ms, 4K 0.203 -> 0.2015, the rank of an 8-way split 0.128 -> 0.126 (profiles/r03_tile32_waves.txt).
 #ifndef VR_RASTER_WAVES_32
 #define VR_RASTER_WAVES_32 6
 #endif
-__global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_WAVES_PER_EU)) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
+__global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_WAVES_PER_EU)) void k_raster(RasterArgs a, DevTex hm, DevTex al, const DevVert* __restrict__ verts,
                                                  const HardTriRec* __restrict__ hard_tris, const uint32_t* __restrict__ hard_first,
                                                  const uint4* __restrict__ recs, uint32_t rec_hard_base,
                                                  const uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_offset,
@@ -1233,8 +1247,10 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                                                  float* __restrict__ g_depth, uint32_t* __restrict__ g_diff, uint32_t* __restrict__ g_spec,
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
                                                  const float* __restrict__ thr_g,
-                                                 const uint8_t* __restrict__ enc_g, uint32_t spec_const, uint2* __restrict__ ranges)
+                                                 const uint8_t* __restrict__ enc_g, uint32_t spec_const, uint2* __restrict__ ranges,
+                                                 typename std::conditional<LIT, LitArgs, LitNone>::type lit)
 {
+    static_assert(!LIT || (MODE == RM_FAST && !RANGES), "the fused variant is the fast variant");
     static_assert((!RANGES && !NOEMI) || MODE == RM_FAST, "depth ranges and the emissive skip come with the fast variant");
     __shared__ unsigned long long vis[TILE * TILE];
     __shared__ __attribute__((aligned(4))) uint8_t enc[(kEncTabSize + 3) / 4 * 4];
@@ -1245,6 +1261,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     // from here by the slot in its visibility word - three LDS reads instead of three fetches per pixel and lane (tile pass alone
     // -2.5 %; profiles/r04_tile_pass_experiments.txt).  Ninety-six lanes fetch them while the sweeps run.
     __shared__ uint4 s_rec[MODE != RM_DEPTH ? 3 * (1 << kTeSlotBits) : 1];
+    __shared__ float s_lut[LIT ? 256 : 1];             // fused variant: the lighting pass's sRGB8 -> linear table
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VR_PROF_BEGIN;
     const int tile = tile_list ? tile_of_block((int)blockIdx.x, tile_list, tile_classes, a.rtx * a.rty) : (int)blockIdx.x;
@@ -1262,6 +1279,8 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
 #pragma unroll
     for (int q = 0; q < kEncPer; q++) enc_r[q] = (!kExpNoTables && tid + q * kRT < kEncWords) ? reinterpret_cast<const uint32_t*>(enc_g)[tid + q * kRT] : 0u;
     const float thr_r = (!kExpNoTables && tid < 256) ? thr_g[tid] : 0.0f;
+    float lut_r = 0.0f;
+    if constexpr (LIT) lut_r = lit.lut_g[tid & 255];
     const uint32_t off = tile_offset[tile], n_all = tile_cursor[tile] - off;     // bin = entries[off .. off + n_all)
     const uint32_t n = min(n_all, off < a.bin_capacity ? a.bin_capacity - off : 0u);   // (an overflowing frame drops the entries beyond the capacity: VR_ERR_OVERFLOW)
     const TileEntry* __restrict__ bin = entries + off;
@@ -1297,6 +1316,7 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
     for (int q = 0; q < kEncPer; q++) if (tid + q * kRT < kEncWords) reinterpret_cast<uint32_t*>(enc)[tid + q * kRT] = enc_r[q];
     if (tid < 256) thr[tid] = thr_r;
     if (tid == 0) thr[256] = __uint_as_float(0x7fc00000u);   // NaN: no x is >= it, not even +inf
+    if (LIT && tid < 256) s_lut[tid] = lut_r;
     __syncthreads();
     VR_PROF_MARK(0);
 
@@ -1605,6 +1625,26 @@ __global__ __launch_bounds__(kRT, (TILE == 32 ? VR_RASTER_WAVES_32 : VR_RASTER_W
                 if (FAST) pixel_shader_fast(a, rq, rc, thr, enc, s_lv, p, dif, nn0, nn1 VR_PROF_ARG);
                 else pixel_shader<false, false>(a, hm, al, rq, rc, thr, enc, s_qoff, s_aoff, p, dif, nn0, nn1);
             }
+            if constexpr (LIT) {
+                // the pixel as the lighting pass would read it back from the G-buffer: the encoded texel (a cleared one where nothing
+                // was drawn), the same decode, the same shading, the same half conversion
+                float lrgb[3];
+                shade_pixel<false>(lit.da, s_lut, gx, gy0 + k, __uint_as_float(dep), dif, cov ? spec_const : 0u, nn0, nn1, 0u, 0u, lrgb);
+                const uint32_t o0 = vr_float_to_half(lrgb[0]) | (vr_float_to_half(lrgb[1]) << 16), o1 = vr_float_to_half(lrgb[2]);
+                __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
+                if (lit.tile_slot == nullptr) {
+                    const u2 ov = { o0, o1 };
+                    __builtin_nontemporal_store(ov, reinterpret_cast<u2*>(lit.hdr) + pix);
+                } else {
+                    // packed tile-major RGB16F (vr_deferred_light's layout for a partition): [local tile][128 rows][128 px] x 6 B
+                    const int otx = gx >> 7, oty = (gy0 + k) >> 7;
+                    const int lt = lit.tile_slot[oty * lit.owner_tiles_x + otx] - lit.slot_base;
+                    const size_t oi = ((size_t)lt * VR_OWNER_TILE + (size_t)((gy0 + k) & 127)) * VR_OWNER_TILE + (size_t)(gx & 127);
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(lit.hdr) + oi * 3;
+                    dst[0] = (uint16_t)o0; dst[1] = (uint16_t)(o0 >> 16); dst[2] = (uint16_t)o1;
+                }
+                continue;
+            }
             if (kExpNoStore) {        // (a dependent dummy keeps the shading alive)
                 if (a.w < 0) __builtin_amdgcn_raw_buffer_store_b32(dep ^ dif ^ nn0 ^ nn1, rgb, pix4, 0, aux);
                 continue;
@@ -1845,10 +1885,42 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     return VR_OK;
 }
 
+// what vr_terrain_render_lit adds to a render: the lighting pass's inputs and its output image
+struct LitRequest { const vr_light* lights; int32_t num_lights; const float* amb_top; const float* amb_bottom; vr_image* hdr; };
+static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp, const vr_partition* part,
+                               const LitRequest* lit_req, bool* lit_done);
+
 extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev, vr_gbuffer* gb,
                                          const vr_render_params* rp, const vr_partition* part)
 {
     (void)view_prev;   // MOTION_VECTORS = 0 (TerrainPass.cpp:361,368)
+    return terrain_render_impl(t, view, gb, rp, part, nullptr, nullptr);
+}
+
+// TerrainPass::Render + DeferredLightingPass::Render in one pass over the pixels (Renderer.cpp:401-428): the tile
+// pass's resolve shades every pixel it has just produced and writes depth + HdrColor; the other four planes of the G-buffer are
+// not written (they keep what they held).  Bit-identical HdrColor and depth to vr_terrain_render(assume_cleared = 1) +
+// vr_deferred_light on the same inputs.  The fused kernel exists for the reference's case (the conditions of the tile pass's
+// fast variant, up to 16 directional / punctual point lights, no shadow term); anything else runs the two passes one after the
+// other inside this call - same result, no saving.
+extern "C" VR_API int vr_terrain_render_lit(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp,
+                                             const vr_partition* part, const vr_light* lights, int32_t num_lights,
+                                             const float ambient_top[3], const float ambient_bottom[3], vr_image* hdr_out)
+{
+    VR_REQUIRE(t && view && gb && rp && hdr_out && ambient_top && ambient_bottom, "NULL argument");
+    VR_REQUIRE(rp->assume_cleared && !rp->depth_only && !rp->wireframe && !rp->depth_ranges,
+               "vr_terrain_render_lit draws into a cleared target (assume_cleared = 1), shaded fill mode, no depth ranges");
+    VR_REQUIRE(num_lights >= 0 && num_lights <= kMaxLights && (num_lights == 0 || lights), "at most 16 lights (terrain_cb.h:15)");
+    const LitRequest req = { lights, num_lights, ambient_top, ambient_bottom, hdr_out };
+    bool fused = false;
+    int rc = terrain_render_impl(t, view, gb, rp, part, &req, &fused);
+    if (rc || fused) return rc;
+    return vr_deferred_light(t->ctx, view, gb, lights, num_lights, ambient_top, ambient_bottom, hdr_out, part);     // the unfused pair
+}
+
+static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp, const vr_partition* part,
+                               const LitRequest* lit_req, bool* lit_done)
+{
     int rc = check_render_inputs(t, view, gb, rp);
     if (rc) return rc;
     vr_context* ctx = t->ctx;
@@ -1907,14 +1979,41 @@ extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, cons
         // plane-state tracking: the emissive plane holds zeros already and the fast variant would only write zeros again
         const bool noemi = fast && ctx->plane_tracking && gb->emissive_zero && !gb->escaped;
         auto kern = a.tile_shift == 5 ? pick_raster<32>(a.wireframe != 0, fast, depth, ranges, noemi) : pick_raster<64>(a.wireframe != 0, fast, depth, ranges, noemi);
-        VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first,
-                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0,
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr);
+        // the fused variant: only where the fast variant applies and the light list is the streaming pass's plain case
+        LitArgs la;
+        bool fuse = false;
+        if (lit_req && fast && !ranges) {
+            bool extra = false;
+            memset(&la, 0, sizeof(la));
+            if ((rc = vr_deferred_make_args(view, gb->w, gb->h, lit_req->lights, lit_req->num_lights, lit_req->amb_top, lit_req->amb_bottom, &la.da, &extra))) return rc;
+            VR_REQUIRE(view->viewport_w == gb->w && view->viewport_h == gb->h && view->viewport_x == 0 && view->viewport_y == 0,
+                       "view viewport must cover the G-buffer");
+            fuse = !extra && gb->w % 4 == 0;
+            if (fuse) {
+                la.lut_g = ctx->d_srgb_lut; la.hdr = (uint2*)lit_req->hdr->data;
+                if (pt) {
+                    VR_REQUIRE((size_t)pt->max_owned * VR_OWNER_TILE * VR_OWNER_TILE * 6 <= lit_req->hdr->capacity_bytes, "hdr_out is smaller than vr_partition_packed_bytes()");
+                    la.tile_slot = pt->d_tile_slot; la.slot_base = pt->rank * pt->max_owned; la.owner_tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
+                    la.da.tiles_x = la.owner_tiles_x;
+                } else VR_REQUIRE((size_t)gb->w * gb->h * 8 <= lit_req->hdr->capacity_bytes, "hdr_out is smaller than the frame");
+            }
+        }
+        if (lit_done) *lit_done = fuse;
+#define VR_RASTER_ARGS a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first, \
+                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0, \
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr
+        if (fuse) {
+            ks.id = VR_K_RASTER_LIT;
+            if (a.tile_shift == 5) VR_LAUNCH_TIMED(ks, (k_raster<false, 32, RM_FAST, false, true, true>), dim3(grid), dim3(kRT), s, VR_RASTER_ARGS, la);
+            else VR_LAUNCH_TIMED(ks, (k_raster<false, 64, RM_FAST, false, true, true>), dim3(grid), dim3(kRT), s, VR_RASTER_ARGS, la);
+        } else
+        VR_LAUNCH_TIMED(ks, kern, dim3(grid), dim3(kRT), s, VR_RASTER_ARGS, LitNone());
+#undef VR_RASTER_ARGS
         if (ctx->dispatch_events && ks.e0 && ks.e1) pass_stop = ks.e1;        // stamped by the dispatch: complete when the tile pass is
         // a shaded pass over a cleared target writes the emissive texel (0) of EVERY pixel of the frame, covered or not: from here
         // on the plane is known zero again, whatever it held (a partitioned or keep-what-is-there pass writes zeros to some pixels:
         // the state stays what it was)
-        if (!noemi && !a.depth_only && a.assume_cleared && a.world <= 1) gb->emissive_zero = true;
+        if (!fuse && !noemi && !a.depth_only && a.assume_cleared && a.world <= 1) gb->emissive_zero = true;     // (the fused variant writes depth only)
     }
     if (pass_stop) { g.raster_done = pass_stop; g.raster_done_epoch = ctx->ev_epoch; }
     else { VR_HIP(hipEventRecord(g.ev_raster_done, s)); g.raster_done = g.ev_raster_done; g.raster_done_epoch = 0; }

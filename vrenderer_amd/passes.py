@@ -393,6 +393,14 @@ class TerrainPass:
                                              render_targets.handle, C.byref(render_params),
                                              C.byref(partition) if partition is not None else None), "vr_terrain_render")
 
+    def RenderLit(self, view, render_targets, render_params, lights, ambient_top, ambient_bottom, output, partition=None):
+        """vr_terrain_render_lit: TerrainPass::Render + DeferredLightingPass::Render fused into the tile pass (opt-in): writes the
+        depth plane and `output` only; same bits as Render(assume_cleared=1) + DeferredLightingPass.Render."""
+        arr = light_array(lights)
+        check(self.ctx.lib.vr_terrain_render_lit(self.handle, C.byref(view), render_targets.handle, C.byref(render_params),
+                                                 C.byref(partition) if partition is not None else None, arr, len(lights),
+                                                 _f3(ambient_top), _f3(ambient_bottom), output.handle), "vr_terrain_render_lit")
+
     def render_stats(self):
         out = (C.c_uint32 * 8)()
         check(self.ctx.lib.vr_debug_render_stats(self.handle, out), "vr_debug_render_stats")
