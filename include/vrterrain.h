@@ -165,7 +165,11 @@ VR_API int  vr_context_synchronize(vr_context* ctx);          /* Renderer::Submi
  * last foreign write) the tile pass does not rewrite it; the plane's contents are the same either way.  vr_gbuffer_upload of the
  * plane ends that knowledge until the next clear or whole-target pass; vr_gbuffer_describe ends it for good (the pointers have left
  * the library), and likewise the depth ranges of vr_render_params::depth_ranges.  0 = every pass writes all five planes. */
-enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE = 3, VR_OPT_PLANE_TRACKING = 4 };
+/* VR_OPT_SCRATCH_WORST_CASE (default 0): a terrain's per-frame scratch (vertices, triangle records, bins: three rotating sets) is sized
+ * by the high-water mark of the node counts its frames select - 1024 nodes to begin with (1.3 GB for the three sets), doubled before a
+ * frame can exceed it - instead of for max_instances (4096: 5 GB).  1 (set BEFORE vr_terrain_create): worst case up front, no growth,
+ * no frame can ever be truncated by the scratch. */
+enum { VR_OPT_ASYNC_GEOMETRY = 1, VR_OPT_DISPATCH_EVENTS = 2, VR_OPT_RASTER_TILE = 3, VR_OPT_PLANE_TRACKING = 4, VR_OPT_SCRATCH_WORST_CASE = 5 };
 VR_API int  vr_context_set_option(vr_context* ctx, int option, int value);
 VR_API const char* vr_last_error(void);
 VR_API const char* vr_version(void);
@@ -239,9 +243,11 @@ VR_API int  vr_terrain_select(vr_terrain* t, const vr_view* view, float max_heig
  * terrain_vs.hlsl, terrain_ps.hlsl; raster state TerrainPass.cpp:460-485).
  * `part` may be NULL (= whole frame on this device).
  * The call is asynchronous.  Conditions only the device can detect - more than max_instances nodes selected
- * (VR_ERR_TOO_MANY_INSTANCES, the reference's assert at TerrainPass.cpp:238), a full bin / clipper work list
- * (VR_ERR_OVERFLOW: triangles were dropped) - are reported by vr_terrain_num_chunks(), which waits for the frame's
- * geometry and returns them; a host that never polls it never sees them. */
+ * (VR_ERR_TOO_MANY_INSTANCES, the reference's assert at TerrainPass.cpp:238), a full bin / clipper work list or a frame that
+ * outgrew the scratch (VR_ERR_OVERFLOW: triangles or nodes were dropped) - are STICKY: every geometry chain leaves its counters
+ * in pinned host memory, and the next vr_terrain_render / vr_terrain_prepare after such a chain has completed returns the code
+ * once (vr_last_error() names the frame's node count).  The call that returns it has still queued its own frame.
+ * vr_terrain_num_chunks() waits for the current frame's geometry and returns its condition directly. */
 VR_API int  vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev,
                               vr_gbuffer* gb, const vr_render_params* rp,
                               const vr_partition* part);

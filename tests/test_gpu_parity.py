@@ -805,6 +805,72 @@ def test_ragged_sizes_and_mismatched_textures(oracle, gpu_ctx):
         ot.close()
 
 
+def test_scratch_grows_by_high_water_mark_and_reports_sticky_conditions(scene2048, oracle, gpu_ctx, monkeypatch):
+    """The per-frame scratch holds cap nodes, not max_instances: it doubles BEFORE a frame can outgrow it (count > cap / 2, read
+    from the pinned counters of completed chains, no wait), and a frame that does outgrow it is drawn without the excess, grows
+    the scratch and is reported - once, sticky - by the next vr_terrain_render; the frame rendered after that is complete.
+    NodeSelect's list never depends on the scratch.  VR_OPT_SCRATCH_WORST_CASE sizes for max_instances up front."""
+    import ctypes as C
+    h, a, ot = scene2048["h"], scene2048["a"], scene2048["ot"]
+    w, hh = 960, 540
+    v = vr.make_view(*CAMERAS[0], w, hh)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    want = oracle.GBufferHost(w, hh)
+    n_o = ot.render(v, want, vr.default_render_params(400.0))
+    assert n_o > 200
+
+    def planes(rt):
+        return {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}
+    # 1. far too small: truncated frame -> sticky VR_ERR_OVERFLOW on the next render -> complete frame
+    monkeypatch.setenv("VR_SCRATCH_INITIAL_NODES", "64")
+    tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, hh)
+    try:
+        small = tp.memory_bytes()["scratch"]
+        n_g, ids_g, _ = tp.NodeSelect(v, 400.0)              # the selection itself is complete whatever the scratch holds
+        assert n_g == n_o
+        small = min(small, tp.memory_bytes()["scratch"])
+        tp2 = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)     # (NodeSelect above has grown tp's scratch already: a fresh one)
+        try:
+            tp2.Render(v, v, rt, rp)                           # 64 of the nodes drawn
+            gpu_ctx.synchronize()
+            assert not np.array_equal(rt.download("depth").view(np.uint32), want.depth.view(np.uint32))
+            rc = gpu_ctx.lib.vr_terrain_render(tp2.handle, C.byref(v), C.byref(v), rt.handle, C.byref(rp), None)
+            assert rc == vr.capi.VR_ERR_OVERFLOW and b"scratch" in gpu_ctx.lib.vr_last_error()
+            _assert_gbuffer_equal(want, planes(rt), "the frame queued by the call that reported the earlier one")
+            assert gpu_ctx.lib.vr_terrain_render(tp2.handle, C.byref(v), C.byref(v), rt.handle, C.byref(rp), None) == vr.capi.VR_OK   # reported once
+            assert tp2.memory_bytes()["scratch"] > 3 * small          # 64 -> 1024 nodes (the bins, clipper lists and selection arrays do not scale with the node count)
+        finally:
+            tp2.close()
+    finally:
+        tp.close()
+    # 2. big enough for the frame but more than half full: grows silently, every frame complete
+    monkeypatch.setenv("VR_SCRATCH_INITIAL_NODES", str(n_o + 8))
+    tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+    try:
+        before = tp.memory_bytes()["scratch"]
+        for k in range(4):
+            tp.Render(v, v, rt, rp)
+            _assert_gbuffer_equal(want, planes(rt), f"frame {k}")
+        assert tp.memory_bytes()["scratch"] > 1.5 * before and tp.num_chunks() == n_o
+    finally:
+        tp.close()
+    monkeypatch.delenv("VR_SCRATCH_INITIAL_NODES")
+    # 3. defaults: 1024 nodes; worst case on request
+    tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+    default_bytes = tp.memory_bytes()["scratch"]
+    tp.close()
+    gpu_ctx.set_scratch_worst_case(True)
+    try:
+        tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+        worst = tp.memory_bytes()["scratch"]
+        tp.close()
+    finally:
+        gpu_ctx.set_scratch_worst_case(False)
+    assert default_bytes < 1.6e9 < 4.0e9 < worst
+    rt.close()
+
+
 def test_too_many_instances_and_empty_selection(scene256, oracle, gpu_ctx):
     """MAX_INSTANCES overflow is an assert in the reference (TerrainPass.cpp:238): here an error code,
     with the first max_instances nodes still in order.  A camera that sees nothing selects nothing."""

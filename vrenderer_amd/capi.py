@@ -26,6 +26,7 @@ VR_OPT_ASYNC_GEOMETRY = 1
 VR_OPT_DISPATCH_EVENTS = 2
 VR_OPT_RASTER_TILE = 3
 VR_OPT_PLANE_TRACKING = 4
+VR_OPT_SCRATCH_WORST_CASE = 5
 
 
 class TerrainParams(C.Structure):

@@ -18,7 +18,9 @@ extern "C" VR_API int vr_frame_submit(vr_terrain* t, vr_gbuffer* gb, const vr_fr
     vr_image* hdr = f->hdr_out;
     int rc;
     // TerrainPass::Render, then the chains of the next frames under its tile pass (a frame already prepared is a no-op)
-    if ((rc = vr_terrain_render(t, f->view, f->view, gb, f->render, f->part))) return rc;
+    // (a sticky code - VR_ERR_TOO_MANY_INSTANCES / VR_ERR_OVERFLOW of an EARLIER frame - does not stop this one: it is returned at the end)
+    int earlier = vr_terrain_render(t, f->view, f->view, gb, f->render, f->part);
+    if (earlier != VR_OK && earlier != VR_ERR_TOO_MANY_INSTANCES && earlier != VR_ERR_OVERFLOW) return earlier;
     for (int k = 0; k < 2; k++)
         if (f->prepare_views[k] && (rc = vr_terrain_prepare(t, f->prepare_views[k], gb, f->render, f->part))) return rc;
     // whoever still reads the image this lighting pass overwrites (the tone-map stage of two frames ago, on another stream)
@@ -27,7 +29,7 @@ extern "C" VR_API int vr_frame_submit(vr_terrain* t, vr_gbuffer* gb, const vr_fr
     else if (f->shadow) rc = vr_deferred_light_shadowed(ctx, f->view, gb, f->lights, f->num_lights, f->ambient_top, f->ambient_bottom, hdr, f->part, f->shadow);
     else rc = vr_deferred_light(ctx, f->view, gb, f->lights, f->num_lights, f->ambient_top, f->ambient_bottom, hdr, f->part);
     if (rc) return rc;
-    if (!f->tonemap) return VR_OK;
+    if (!f->tonemap) return earlier;
 
     // ToneMappingPass::SimpleRender on the tone mapper's own context (another stream: it runs under the next frame's rendering)
     VR_REQUIRE(f->tonemap_params && f->ldr_out, "tone-map stage: params / ldr_out missing");
@@ -59,5 +61,5 @@ extern "C" VR_API int vr_frame_submit(vr_terrain* t, vr_gbuffer* gb, const vr_fr
         VR_REQUIRE(f->part && f->gathered && f->ldr_frame, "exchange: partition / gathered / ldr_frame missing");
         if ((rc = vr_frame_allgather_ldr(tc, f->nccl_comm, f->ldr_out, f->gathered, f->part->world_size, w, h, f->ldr_frame))) return rc;
     }
-    return VR_OK;
+    return earlier;
 }

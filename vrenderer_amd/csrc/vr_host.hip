@@ -99,9 +99,10 @@ extern "C" VR_API int vr_context_set_stream(vr_context* c, void* s)
 extern "C" VR_API int vr_context_set_option(vr_context* c, int option, int value)
 {
     VR_REQUIRE(c != nullptr, "ctx is NULL");
-    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS || option == VR_OPT_RASTER_TILE || option == VR_OPT_PLANE_TRACKING, "unknown option");
+    VR_REQUIRE(option == VR_OPT_ASYNC_GEOMETRY || option == VR_OPT_DISPATCH_EVENTS || option == VR_OPT_RASTER_TILE || option == VR_OPT_PLANE_TRACKING || option == VR_OPT_SCRATCH_WORST_CASE, "unknown option");
     if (option == VR_OPT_ASYNC_GEOMETRY) c->async_geometry = value != 0;
     else if (option == VR_OPT_PLANE_TRACKING) c->plane_tracking = value != 0;
+    else if (option == VR_OPT_SCRATCH_WORST_CASE) c->scratch_worst_case = value != 0;
     else if (option == VR_OPT_RASTER_TILE) {
         VR_REQUIRE(value == 0 || value == 32 || value == 64, "VR_OPT_RASTER_TILE: 0 (by size), 32 or 64");
         c->raster_tile_force = value == 32 ? 5 : value == 64 ? 6 : 0;
@@ -202,6 +203,16 @@ extern "C" VR_API int vr_timing_enable(vr_context* c, int enable)
     for (hipEvent_t e : c->ev_end) (void)hipEventSynchronize(e);
     timing_reset(c);
     c->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    // events for the launches to come are made HERE, not one by one inside the host's frame loop (hipEventCreate per stamped
+    // launch was ~20 us of a rank's ~100 us of host time per frame): enough for a few hundred frames, more are made on demand
+    if (c->timing) {
+        const size_t want = c->timing == 1 ? 8192 : 2048;
+        while (c->ev_pool.size() < want) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, vr_event_flags()) != hipSuccess) break;
+            c->ev_pool.push_back(e);
+        }
+    }
     return VR_OK;
 }
 extern "C" VR_API int vr_timing_collect(vr_context* c, float ms_sum[VR_K_COUNT], int32_t launches[VR_K_COUNT])

@@ -157,6 +157,7 @@ struct vr_context {
     // shadow map's and the main view's geometry every frame)
     std::vector<PartTables*> part_tables;
     bool async_geometry = true;    // VR_OPT_ASYNC_GEOMETRY
+    bool scratch_worst_case = false;   // VR_OPT_SCRATCH_WORST_CASE: terrains created from now on size their scratch for max_instances up front
     bool plane_tracking = true;    // VR_OPT_PLANE_TRACKING: the tile pass does not rewrite a G-buffer plane the library knows to be all zero (vr_gbuffer)
     int raster_tile_force = 0;     // VR_OPT_RASTER_TILE: 0 = by size (vr_raster_tile_shift), 5 / 6 = 32- / 64-pixel raster tiles
     // VR_OPT_DISPATCH_EVENTS: the tile pass and the lighting pass are launched with hipExtLaunchKernelGGL, whose start/stop
@@ -287,6 +288,7 @@ struct GeoSet {
     // frames have their latency-bound chains in flight at once).
     hipStream_t stream = nullptr;
     bool main_dep_pending = false;       // the context's stream changed the terrain (node heights): wait for ev_main_dep first
+    bool status_pending = false;         // the last chain's counters have not been read from the host mirror yet
     // vr_terrain_prepare: geometry already built for exactly these inputs
     bool prepared = false;
     uint64_t prep_serial = 0;            // order of the vr_terrain_prepare calls (the oldest prepared set is evicted first)
@@ -303,6 +305,18 @@ struct vr_terrain {
     uint64_t bytes_textures = 0, bytes_scratch = 0;     // vr_terrain_memory_bytes
     uint32_t extra_vert_cap = 0, hard_cap = 0;
     size_t bin_capacity = 0;
+    // Per-frame scratch by HIGH-WATER MARK (round 4): vertices, triangle records and bins are sized for cap_instances nodes - not
+    // for params.max_instances (4096: 1.7 GB per geometry set, of which an 8K frame's ~300 nodes use a few percent).  Every
+    // chain leaves its counters in a pinned host mirror (k_fill's first act); the next API call reads the mirrors of the chains that
+    // have completed (hipEventQuery, no wait), keeps the largest node count seen and doubles the scratch BEFORE a frame can
+    // exceed it (count > half the capacity).  A frame that does exceed it - the count more than doubled within three frames -
+    // is drawn without the excess nodes and reported like the other device-side conditions: sticky, by the next vr_terrain_render.
+    int cap_instances = 0;
+    uint32_t* h_status = nullptr;          // kGeoSets x 8 words, hipHostMalloc (mapped)
+    uint32_t* d_status = nullptr;          // the device's view of it
+    uint32_t high_water = 0;               // most nodes a completed frame selected
+    int sticky_error = 0;                  // VR_ERR_* of a completed frame, not yet reported
+    uint32_t sticky_count = 0;
     GeoSet sets[kGeoSets];
     int cur = 0;                            // set of the most recent select / render
     uint64_t prep_counter = 0;
@@ -334,6 +348,9 @@ int vr_tex_upload_and_mip(vr_context* ctx, const uint8_t* host, int w, int h, in
                           DevTex* out, uint8_t** out_mem, uint64_t* out_bytes = nullptr);
 int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_height, hipStream_t stream);
 int vr_terrain_pick_set(vr_terrain* t);
+// reads the counters of completed chains (no wait), grows the scratch by the high-water mark; returns a completed frame's sticky
+// device-side error once (VR_OK otherwise).  Called at the head of vr_terrain_render / vr_terrain_prepare / vr_terrain_select.
+int vr_terrain_poll(vr_terrain* t, bool report);
 // tables of (w, h, part); part == NULL is the whole frame as rank 0 of 1
 int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out);
 // any cached table set of (w, h, world): the slot table does not depend on the rank

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void k_vertex(VertexArgs a, DevTex hm, const v
                                                  uint32_t* __restrict__ counters, DevVert* __restrict__ verts)
 {
     VR_GEOMETRY_PRIORITY();
-    // first kernel of every frame: reset the frame's work counters (k_setup is the first to use them)
-    if (blockIdx.x == 0 && threadIdx.x < 14) counters[2 + threadIdx.x] = 0u;
+    // first kernel of every frame: reset the frame's work counters (k_setup is the first to use them); words 6 and 7 are
+    // k_select's (the selection's size before truncation, NodeSelect's count) and stay
+    if (blockIdx.x == 0 && threadIdx.x < 14 && (threadIdx.x < 4 || threadIdx.x >= 6)) counters[2 + threadIdx.x] = 0u;
     __shared__ float r8[256];
     __shared__ uint32_t s_qoff[kMaxLevels];
     r8[threadIdx.x] = (float)threadIdx.x / 255.0f;     // UNORM8 -> float, correctly rounded
@@ -711,9 +712,12 @@ __global__ __launch_bounds__(64) void k_clip(RasterArgs a, DevVert* __restrict__
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fill(RasterArgs a, const uint32_t* __restrict__ counters, const uint64_t* __restrict__ rect,
                                                const HardTriRec* __restrict__ hard_tris, const uint4* __restrict__ recs, uint32_t rec_hard_base,
-                                               uint32_t* __restrict__ tile_cursor, TileEntry* __restrict__ entries)
+                                               uint32_t* __restrict__ tile_cursor, TileEntry* __restrict__ entries, uint32_t* __restrict__ status)
 {
     VR_GEOMETRY_PRIORITY();
+    // the chain's counters (node count, status flags, work-list lengths: all final before this launch) into the terrain's pinned
+    // host mirror: the host reads them without a wait once the chain's event has completed (vr_terrain_poll)
+    if (blockIdx.x == 0 && threadIdx.x < 8) { __hip_atomic_store(&status[threadIdx.x], counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     const uint32_t n_reg = counters[C_COUNT] * (uint32_t)kTrisPerInst;
     const uint32_t n_hard = min(counters[C_HARDTRIS], a.hard_cap * 4u);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reg + n_hard; i += gridDim.x * blockDim.x) {
@@ -1726,7 +1730,7 @@ static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_
     { uint32_t wb; memcpy(&wb, &t->p.world_size, 4); a.ws_pow2 = (wb & 0x7fffffu) == 0u && t->p.world_size >= 1.0f && t->p.world_size <= 65536.0f; }
     a.lod_w = (float)t->height.w0 * a.inv_world_size; a.lod_h = (float)t->height.h0 * a.inv_world_size; a.max_level_f = (float)(t->height.levels - 1);
     a.bin_capacity = (uint32_t)t->bin_capacity;
-    a.extra_vert_base = (uint32_t)t->p.max_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
+    a.extra_vert_base = (uint32_t)t->cap_instances * kVertsPerInst; a.extra_vert_cap = t->extra_vert_cap; a.hard_cap = t->hard_cap;
     a.vp_x = (float)view->viewport_x; a.vp_y = (float)view->viewport_y; a.vp_w = (float)view->viewport_w; a.vp_h = (float)view->viewport_h;
     return VR_OK;
 }
@@ -1801,7 +1805,7 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
     hipLaunchKernelGGL(k_setup, dim3(kGridSetup), dim3(256), 0, gs, a, g.d_verts, g.d_counters, g.d_rect, g.d_hard_list, g.d_tile_count, g.d_recs); }
     { VrKernelScope ks(ctx, VR_K_CLIP, gs);
     hipLaunchKernelGGL(k_clip, dim3(64), dim3(64), 0, gs, a, g.d_verts, g.d_counters, g.d_hard_list, g.d_hard_tris, g.d_hard_first, g.d_tile_count,
-                       g.d_recs + (size_t)t->p.max_instances * kTrisPerInst * kRecGroups); }
+                       g.d_recs + (size_t)t->cap_instances * kTrisPerInst * kRecGroups); }
     { VrKernelScope ks(ctx, VR_K_SCAN, gs);
     const bool whole = pt == nullptr;
     const int n_scan = whole ? n_tiles : pt->num_raster_tiles;
@@ -1811,7 +1815,8 @@ static int launch_geometry(vr_terrain* t, GeoSet& g, GeoSet* selection_from, con
                            g.d_tile_order); }
     { VrKernelScope ks(ctx, VR_K_FILL, gs);
     hipLaunchKernelGGL(k_fill, dim3(kGridFill), dim3(256), 0, gs, a, g.d_counters, g.d_rect, g.d_hard_tris, (const uint4*)g.d_recs,
-                       (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_bin_entries); }
+                       (uint32_t)t->cap_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_bin_entries, t->d_status + (size_t)(&g - t->sets) * 8); }
+    g.status_pending = true;
     VR_HIP(hipEventRecord(g.ev_geo_done, gs));
     g.geo_recorded = true;
     VR_HIP(hipGetLastError());
@@ -1851,6 +1856,8 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     if (rc) return rc;
     VR_REQUIRE(!rp->lock_view, "vr_terrain_prepare builds a new selection; it cannot be combined with lock_view");
     VR_HIP(hipSetDevice(t->ctx->device));
+    // completed chains' counters: the scratch grows here if due (a sticky condition is vr_terrain_render's to report)
+    if ((rc = vr_terrain_poll(t, false))) return rc;
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
@@ -1888,13 +1895,15 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
 // what vr_terrain_render_lit adds to a render: the lighting pass's inputs and its output image
 struct LitRequest { const vr_light* lights; int32_t num_lights; const float* amb_top; const float* amb_bottom; vr_image* hdr; };
 static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp, const vr_partition* part,
-                               const LitRequest* lit_req, bool* lit_done);
+                               const LitRequest* lit_req, bool* lit_done, int* earlier_out);
 
 extern "C" VR_API int vr_terrain_render(vr_terrain* t, const vr_view* view, const vr_view* view_prev, vr_gbuffer* gb,
                                          const vr_render_params* rp, const vr_partition* part)
 {
     (void)view_prev;   // MOTION_VECTORS = 0 (TerrainPass.cpp:361,368)
-    return terrain_render_impl(t, view, gb, rp, part, nullptr, nullptr);
+    int earlier = VR_OK;
+    const int rc = terrain_render_impl(t, view, gb, rp, part, nullptr, nullptr, &earlier);
+    return rc ? rc : earlier;          // this frame is queued either way; `earlier` = a completed frame's device-side condition (sticky, once)
 }
 
 // TerrainPass::Render + DeferredLightingPass::Render in one pass over the pixels (Renderer.cpp:401-428): the tile
@@ -1913,19 +1922,25 @@ extern "C" VR_API int vr_terrain_render_lit(vr_terrain* t, const vr_view* view, 
     VR_REQUIRE(num_lights >= 0 && num_lights <= kMaxLights && (num_lights == 0 || lights), "at most 16 lights (terrain_cb.h:15)");
     const LitRequest req = { lights, num_lights, ambient_top, ambient_bottom, hdr_out };
     bool fused = false;
-    int rc = terrain_render_impl(t, view, gb, rp, part, &req, &fused);
-    if (rc || fused) return rc;
-    return vr_deferred_light(t->ctx, view, gb, lights, num_lights, ambient_top, ambient_bottom, hdr_out, part);     // the unfused pair
+    int earlier = VR_OK;
+    int rc = terrain_render_impl(t, view, gb, rp, part, &req, &fused, &earlier);
+    if (rc) return rc;
+    if (!fused && (rc = vr_deferred_light(t->ctx, view, gb, lights, num_lights, ambient_top, ambient_bottom, hdr_out, part))) return rc;     // the unfused pair
+    return earlier;
 }
 
 static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* gb, const vr_render_params* rp, const vr_partition* part,
-                               const LitRequest* lit_req, bool* lit_done)
+                               const LitRequest* lit_req, bool* lit_done, int* earlier_out)
 {
     int rc = check_render_inputs(t, view, gb, rp);
     if (rc) return rc;
     vr_context* ctx = t->ctx;
     VR_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    // what earlier frames' chains left in the host mirror: grows the scratch if due, and a device-side condition of a completed
+    // frame (too many nodes, a full work list) is returned - once - behind this frame's launches
+    const int earlier = vr_terrain_poll(t, true);
+    if (earlier && earlier != VR_ERR_OVERFLOW && earlier != VR_ERR_TOO_MANY_INSTANCES) return earlier;     // (the scratch could not grow)
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
@@ -2000,7 +2015,7 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
         }
         if (lit_done) *lit_done = fuse;
 #define VR_RASTER_ARGS a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first, \
-                           (const uint4*)g.d_recs, (uint32_t)t->p.max_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0, \
+                           (const uint4*)g.d_recs, (uint32_t)t->cap_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0, \
                            gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr
         if (fuse) {
             ks.id = VR_K_RASTER_LIT;
@@ -2022,6 +2037,7 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
     for (GeoSet& p : t->sets)
         if (&p != &g && p.prepared && !(p.main_waited && p.main_wait_stream == s) && p.geo_recorded) { VR_HIP(hipStreamWaitEvent(s, p.ev_geo_done, 0)); p.main_waited = true; p.main_wait_stream = s; }
     VR_HIP(hipGetLastError());
+    if (earlier_out) *earlier_out = earlier;
     return VR_OK;
 }
 

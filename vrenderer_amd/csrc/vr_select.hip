@@ -36,6 +36,7 @@ struct SelectArgs {
     float half_w, half_h;        // root extents (m_Width/2, m_Height/2)
     int num_lods;
     int max_instances;
+    int cap_instances;           // what the scratch of this frame holds (<= max_instances)
     int height_loaded;           // m_HeightLoaded
     float max_height;
     // multi-surface worlds (TerrainPass.cpp:97-110): one quadtree per surface
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     // (LDS broadcast reads).
     uint32_t total = n_sel;
     if (total > (uint32_t)kSelectedCap) total = kSelectedCap;
-    const uint32_t limit = min(total, (uint32_t)a.max_instances);
+    const uint32_t limit = min(total, (uint32_t)a.max_instances);             // ids and instances: the selection itself (their arrays hold max_instances)
     constexpr int kOwn = kSelectedCap / kSelThreads;
     const int own_n = (int)((total + kSelThreads - 1) / kSelThreads);        // keys per thread that exist at all (uniform; 2 for ~300 nodes)
     uint32_t key[kOwn], rank[kOwn];
@@ -241,9 +242,12 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a, uint32_t* 
     if (tid == 0) for (int q = 0; q < 4; q++) { selected[kSelectedCap - 8 + 2 * q] = (uint32_t)prof_t[q]; selected[kSelectedCap - 7 + 2 * q] = (uint32_t)(prof_t[q] >> 32); }
 #endif
     if (tid == 0) {
-        counters[0] = limit;
+        counters[0] = min(limit, (uint32_t)a.cap_instances);                   // what the rest of the chain draws: as many as its scratch holds
+        counters[7] = limit;                                                   // what NodeSelect returns
         uint32_t flags = 0;
         if (n_sel > (uint32_t)a.max_instances) flags |= 1u;      // VR_ERR_TOO_MANY_INSTANCES
+        else if (n_sel > (uint32_t)a.cap_instances) flags |= 4u; // more than the scratch holds (it grows: vr_terrain_poll)
+        counters[6] = n_sel;                                     // the count before any truncation (the scratch's high-water mark)
         if (overflow) flags |= 2u;                               // VR_ERR_OVERFLOW
         counters[1] = flags;
     }
@@ -256,7 +260,7 @@ int vr_select_launch(vr_terrain* t, GeoSet& g, const vr_view* view, float max_he
     for (int i = 0; i < 6; i++) for (int j = 0; j < 4; j++) a.planes[i][j] = view->planes[i][j];
     for (int i = 0; i < VR_MAX_LODS; i++) a.range2[i] = t->lod_ranges[i] * t->lod_ranges[i];
     a.half_w = t->p.surface_size / 2.0f; a.half_h = t->p.surface_size / 2.0f;
-    a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.max_height = max_height;
+    a.num_lods = t->num_lods; a.max_instances = t->p.max_instances; a.cap_instances = t->cap_instances; a.max_height = max_height;
     a.height_loaded = (t->height_loaded && t->d_node_heights) ? 1 : 0;
     a.surfaces_per_side = t->surfaces_per_side; a.num_surfaces = t->surfaces_per_side * t->surfaces_per_side;
     a.surface_size = t->p.surface_size;
@@ -467,6 +471,80 @@ extern "C" VR_API int vr_terrain_download_node_heights(vr_terrain* t, uint32_t f
 }
 
 // ---- terrain object -------------------------------------------------------------------
+// The part of a terrain's per-frame scratch that scales with the number of nodes a frame selects (vr_terrain::cap_instances).
+static void free_scratch(vr_terrain* t)
+{
+    for (GeoSet& g : t->sets) {
+        (void)hipFree(g.d_verts); (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_first); (void)hipFree(g.d_bin_entries);
+        g.d_verts = nullptr; g.d_rect = nullptr; g.d_recs = nullptr; g.d_hard_first = nullptr; g.d_bin_entries = nullptr;
+    }
+}
+static int alloc_scratch(vr_terrain* t, int cap)
+{
+    free_scratch(t);
+    const size_t mi = (size_t)cap, fixed = (size_t)t->p.max_instances * (sizeof(uint32_t) + sizeof(vr_instance)) + 64 * sizeof(uint32_t)
+                    + kSelScratchWords * sizeof(uint32_t) + (size_t)t->hard_cap * (sizeof(uint32_t) + 4 * sizeof(HardTriRec));
+    t->bytes_scratch = (uint64_t)fixed * kGeoSets;
+    // (triangle, tile) pairs: an 8K frame of ~300 nodes has ~0.3 M, a 1080p frame ~0.6 M; 1 M per 1024 nodes and never fewer
+    t->bin_capacity = ((size_t)1 << 20) * ((mi + 1023) / 1024);
+#define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
+        vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } \
+        t->bytes_scratch += (uint64_t)(bytes); } while (0)
+    for (GeoSet& g : t->sets) {
+        VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
+        VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
+        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * kRecGroups * sizeof(uint4));
+        VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
+        VR_ALLOC(g.d_bin_entries, t->bin_capacity * sizeof(TileEntry));
+        g.prepared = false;                   // geometry built for the old buffers is gone (a selection lives in the fixed part: kept)
+    }
+#undef VR_ALLOC
+    t->cap_instances = cap;
+    return VR_OK;
+}
+
+int vr_terrain_poll(vr_terrain* t, bool report)
+{
+    uint32_t seen = 0;
+    for (int i = 0; i < kGeoSets; i++) {
+        GeoSet& g = t->sets[i];
+        if (!g.status_pending || !g.geo_recorded || hipEventQuery(g.ev_geo_done) != hipSuccess) continue;
+        g.status_pending = false;
+        const volatile uint32_t* st = t->h_status + i * 8;
+        const uint32_t flags = st[1], wanted = st[6];
+        if (wanted > seen) seen = wanted;
+        if (flags & 1u) { t->sticky_error = VR_ERR_TOO_MANY_INSTANCES; t->sticky_count = wanted; }
+        else if (flags & 6u) { if (!t->sticky_error) t->sticky_error = VR_ERR_OVERFLOW; t->sticky_count = wanted; }
+    }
+    if (seen > t->high_water) t->high_water = seen;
+    // grow before a frame can outgrow the scratch: twice the largest count seen, once that passes half the capacity
+    const int max_i = t->p.max_instances;
+    if (t->cap_instances < max_i && (size_t)t->high_water * 2 > (size_t)t->cap_instances) {
+        int want = t->cap_instances;
+        while (want < max_i && (size_t)t->high_water * 2 > (size_t)want) want *= 2;
+        if (want > max_i) want = max_i;
+        VR_HIP(hipSetDevice(t->ctx->device));
+        for (hipStream_t gs : t->geo_streams) VR_HIP(hipStreamSynchronize(gs));
+        VR_HIP(hipStreamSynchronize(t->ctx->stream));
+        const int had = t->cap_instances;
+        int rc = alloc_scratch(t, want);
+        if (rc) {
+            // the larger scratch does not fit: back to the old size (frames that need more stay truncated and reported)
+            const int rc2 = alloc_scratch(t, had);
+            t->high_water = 0;
+            return rc2 ? rc2 : rc;
+        }
+    }
+    if (report && t->sticky_error) {
+        const int e = t->sticky_error;
+        t->sticky_error = VR_OK;
+        if (e == VR_ERR_TOO_MANY_INSTANCES) vr_set_error("an earlier frame selected %u nodes, more than max_instances (TerrainPass.cpp:238 assert); it was drawn without the excess", t->sticky_count);
+        else vr_set_error("an earlier frame (%u nodes) overflowed a work list or the scratch: triangles or nodes were dropped (the scratch now holds %d nodes)", t->sticky_count, t->cap_instances);
+        return e;
+    }
+    return VR_OK;
+}
+
 static int ilog2_floor(float x)
 {
     uint32_t b; memcpy(&b, &x, 4);
@@ -502,24 +580,25 @@ extern "C" VR_API int vr_terrain_create(vr_context* ctx, const vr_terrain_params
     if ((rc = vr_tex_upload_and_mip(ctx, albedo, al_w, al_h, 4, &t->albedo, &t->d_albedo, &t->bytes_textures))) return rc;
     const size_t mi = (size_t)params->max_instances;
     t->extra_vert_cap = 1u << 16; t->hard_cap = 1u << 15;
-#define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
-        vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } \
-        t->bytes_scratch += (uint64_t)(bytes); } while (0)
-    t->bin_capacity = (size_t)4 << 20;             // (triangle, tile) pairs per frame: an 8K frame has ~0.2 M, a 1080p frame ~0.6 M; beyond -> VR_ERR_OVERFLOW
-    for (GeoSet& g : t->sets) {
-        VR_ALLOC(g.d_node_ids, mi * sizeof(uint32_t));
-        VR_ALLOC(g.d_instances, mi * sizeof(vr_instance));
-        VR_ALLOC(g.d_counters, 64 * sizeof(uint32_t));
-        VR_ALLOC(g.d_sel_scratch, kSelScratchWords * sizeof(uint32_t));
-        VR_ALLOC(g.d_verts, (mi * kVertsPerInst + t->extra_vert_cap) * sizeof(DevVert));
-        VR_ALLOC(g.d_rect, mi * kTrisPerInst * sizeof(uint64_t));
-        VR_ALLOC(g.d_recs, (mi * kTrisPerInst + (size_t)t->hard_cap * 4) * kRecGroups * sizeof(uint4));
-        VR_ALLOC(g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
-        VR_ALLOC(g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
-        VR_ALLOC(g.d_hard_first, mi * kTrisPerInst * sizeof(uint32_t));
-        VR_ALLOC(g.d_bin_entries, t->bin_capacity * sizeof(TileEntry));
+    for (GeoSet& g : t->sets) {         // what does not depend on the scratch's capacity
+        hipError_t e_ = hipMalloc(&g.d_node_ids, mi * sizeof(uint32_t));
+        if (e_ == hipSuccess) e_ = hipMalloc(&g.d_instances, mi * sizeof(vr_instance));
+        if (e_ == hipSuccess) e_ = hipMalloc(&g.d_counters, 64 * sizeof(uint32_t));
+        if (e_ == hipSuccess) e_ = hipMalloc(&g.d_sel_scratch, kSelScratchWords * sizeof(uint32_t));
+        if (e_ == hipSuccess) e_ = hipMalloc(&g.d_hard_list, (size_t)t->hard_cap * sizeof(uint32_t));
+        if (e_ == hipSuccess) e_ = hipMalloc(&g.d_hard_tris, (size_t)t->hard_cap * 4 * sizeof(HardTriRec));
+        if (e_ != hipSuccess) { vr_set_error("hipMalloc failed: %s", hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; }
     }
-#undef VR_ALLOC
+    VR_HIP(hipHostMalloc((void**)&t->h_status, kGeoSets * 8 * sizeof(uint32_t), hipHostMallocMapped));
+    memset(t->h_status, 0, kGeoSets * 8 * sizeof(uint32_t));
+    VR_HIP(hipHostGetDevicePointer((void**)&t->d_status, t->h_status, 0));
+    {   // what the scratch holds to begin with: 1024 nodes (a 2048^2 world selects 300-600), or everything (VR_OPT_SCRATCH_WORST_CASE);
+        // VR_SCRATCH_INITIAL_NODES (environment) lets a test start smaller and watch it grow
+        int initial = 1024;
+        if (const char* e = getenv("VR_SCRATCH_INITIAL_NODES")) { const int v = atoi(e); if (v >= 1) initial = v; }
+        if (ctx->scratch_worst_case || initial > (int)mi) initial = (int)mi;
+        if ((rc = alloc_scratch(t, initial))) return rc;
+    }
     for (GeoSet& g : t->sets) {
         VR_HIP(hipMemsetAsync(g.d_counters, 0, 64 * sizeof(uint32_t), ctx->stream));
         VR_HIP(hipEventCreateWithFlags(&g.ev_geo_done, hipEventDisableTiming));
@@ -555,10 +634,12 @@ extern "C" VR_API void vr_terrain_destroy(vr_terrain* t)
         if (g.ev_geo_done) (void)hipEventDestroy(g.ev_geo_done);
         if (g.ev_raster_done) (void)hipEventDestroy(g.ev_raster_done);
         if (g.ev_sel_read) (void)hipEventDestroy(g.ev_sel_read);
-        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_sel_scratch); (void)hipFree(g.d_verts);
-        (void)hipFree(g.d_rect); (void)hipFree(g.d_recs); (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris); (void)hipFree(g.d_hard_first);
-        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order); (void)hipFree(g.d_bin_entries);
+        (void)hipFree(g.d_node_ids); (void)hipFree(g.d_instances); (void)hipFree(g.d_counters); (void)hipFree(g.d_sel_scratch);
+        (void)hipFree(g.d_hard_list); (void)hipFree(g.d_hard_tris);
+        (void)hipFree(g.d_tile_count); (void)hipFree(g.d_tile_offset); (void)hipFree(g.d_tile_cursor); (void)hipFree(g.d_tile_order);
     }
+    free_scratch(t);
+    if (t->h_status) (void)hipHostFree(t->h_status);
     (void)hipFree(t->d_height); (void)hipFree(t->d_albedo); (void)hipFree(t->d_node_heights); (void)hipFree(t->d_minmax);
     delete t;
 }
@@ -591,15 +672,26 @@ extern "C" VR_API int vr_terrain_download_mip(vr_terrain* t, int which, int leve
     return VR_OK;
 }
 
-static int read_counters(vr_terrain* t, uint32_t* count)
+static int read_counters(vr_terrain* t, uint32_t* count, bool selection_only = false)
 {
-    uint32_t c[4] = { 0, 0, 0, 0 };
+    uint32_t c[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     VR_HIP(hipStreamSynchronize(t->sets[t->cur].stream)); // selection and bins are produced on the set's geometry stream
     VR_HIP(hipMemcpyAsync(c, t->sets[t->cur].d_counters, sizeof(c), hipMemcpyDeviceToHost, t->ctx->stream));
     VR_HIP(hipStreamSynchronize(t->ctx->stream));
-    if (count) *count = c[0];
-    if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
+    if (count) *count = selection_only ? c[7] : c[0];           // NodeSelect's list is complete up to max_instances whatever the scratch holds
+    t->sets[t->cur].status_pending = false;                     // read here; not reported a second time
     if (c[1] & 1u) { vr_set_error("more than max_instances nodes selected (TerrainPass.cpp:238 assert)"); return VR_ERR_TOO_MANY_INSTANCES; }
+    if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
+    if (c[1] & 4u) {
+        // the frame wanted more nodes than the scratch held: grow now, so that rendering the frame again is complete
+        if (c[6] > t->high_water) t->high_water = c[6];
+        (void)vr_terrain_poll(t, false);
+        if (selection_only) return VR_OK;                       // (a selection alone needs no scratch)
+        t->sticky_error = VR_OK;
+        vr_set_error("the frame selected more nodes than the scratch held (drawn without the excess); the scratch has been grown to %d nodes - render again",
+                     t->cap_instances);
+        return VR_ERR_OVERFLOW;
+    }
     return VR_OK;
 }
 
@@ -621,6 +713,8 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
 {
     VR_REQUIRE(t && view, "NULL argument");
     VR_HIP(hipSetDevice(t->ctx->device));
+    // (grows the scratch if due; a sticky condition of an earlier frame is vr_terrain_render's to report)
+    { const int prc = vr_terrain_poll(t, false); if (prc) return prc; }
     // the selection buffers are consumed by geometry-stream kernels: order this launch behind them and
     // behind whatever the context's stream did to the terrain (heights)
     const int gi = vr_terrain_pick_set(t);                         // a set no tile pass in flight is reading
@@ -639,7 +733,7 @@ extern "C" VR_API int vr_terrain_select(vr_terrain* t, const vr_view* view, floa
     t->cur = gi;
     if (!node_ids && !instances && !count) return VR_OK;       // stays asynchronous
     uint32_t n = 0;
-    rc = read_counters(t, &n);
+    rc = read_counters(t, &n, true);
     if (count) *count = n;
     if (node_ids && n) VR_HIP(hipMemcpy(node_ids, g.d_node_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (instances && n) VR_HIP(hipMemcpy(instances, g.d_instances, n * sizeof(vr_instance), hipMemcpyDeviceToHost));

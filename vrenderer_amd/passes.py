@@ -48,6 +48,10 @@ class Context:
         """The tile pass does not rewrite a G-buffer plane the library knows to be all zero (the emissive plane; default on)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_PLANE_TRACKING, int(enable)), "vr_context_set_option")
 
+    def set_scratch_worst_case(self, enable):
+        """Terrains created from now on size their per-frame scratch for max_instances up front instead of by high-water mark."""
+        check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_SCRATCH_WORST_CASE, int(enable)), "vr_context_set_option")
+
     def set_dispatch_events(self, enable):
         """Tile pass / lighting pass launched with dispatch-stamped events that double as cross-stream dependencies (default on)."""
         check(self.lib.vr_context_set_option(self.handle, capi.VR_OPT_DISPATCH_EVENTS, int(enable)), "vr_context_set_option")
