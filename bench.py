@@ -659,7 +659,7 @@ def main():
         # reads, + WRITE_SIZE; see tools/summarize_pmc.py).  They were taken on the N=1 8K workload.
         pmc, sq = {}, {}
         def newest(stem):
-            for rnd in ("r03", "r02"):
+            for rnd in ("r04", "r03", "r02"):
                 f = f"profiles/{rnd}_{stem}"
                 if os.path.exists(os.path.join(ROOT, f)):
                     return f
@@ -699,21 +699,39 @@ def main():
         def roof_valu(name):
             """Vector-instruction issue of the tile pass / the tiled lighting pass.  achieved = wave-instructions per launch
             (SQ_INSTS_VALU from the committed PMC pass of this command) / the live HIP-event duration.  peak = one wave64
-            instruction per cycle and SIMD, the rate tools/micro/valu_cost.hip measures for the cheapest class (v_mul/v_add/
-            v_fma_f32 with register operands, 8 waves per SIMD: 0.99 cycles; profiles/r03_valu_issue_costs.txt); most other
-            VALU instructions of these kernels (conversions, v_med3, 24-bit mads, compares, selects, anything with a scalar
-            operand) cost 2 cycles there, and a wave issues at most one VALU instruction per ~4.75 cycles, so at the 4 waves
-            per SIMD these kernels run with (registers, LDS) the ceiling is 4 / 4.75 = 0.84 per cycle: peak_at_occupancy."""
+            instruction per TWO cycles and SIMD: the cheapest class (v_mul / v_add / v_fma_f32, moves, 32-bit integer adds and
+            logic with register operands) occupies a SIMD-32 for 2 cycles - round 4's calibration by wall time x the launch's
+            clock (tools/micro/valu_cost.hip, profiles/r04_valu_issue_costs.txt; round 3's table read 1 cycle from a median
+            wave's ticks, which the age-based arbitration halves).  Conversions, v_med3, 24-bit mads, shifts, compares,
+            selects and anything with a scalar operand cost 4, transcendentals 8.  pipe_busy = the launch's class counters
+            priced with those costs / (1024 SIMDs x clock x duration): the share of the vector pipes' cycles that are taken,
+            with the 32-bit integer class (adds and logic at 2, the rest at 4: not split by the counters) at both ends."""
             if name not in timings or name not in sq:
                 return None
             ms, n = timings[name]
             avg_s = ms / n * 1e-3
-            ach = sq[name]["SQ_INSTS_VALU"] / avg_s / 1e9
-            peak = 1024 * 2.4
-            return {"kernel": name, "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                    "frac": round(ach / peak, 4), "peak_at_occupancy": round(peak * 4.0 / 4.75, 1), "frac_at_occupancy": round(ach / (peak * 4.0 / 4.75), 4),
-                    "insts_per_launch": sq[name]["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
-                    "source": sq_file + ", profiles/r03_valu_issue_costs.txt"}
+            c = sq[name]
+            ach = c["SQ_INSTS_VALU"] / avg_s / 1e9
+            peak = 1024 * 2.4 / 2.0
+            out = {"kernel": name, "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                   "frac": round(ach / peak, 4), "insts_per_launch": c["SQ_INSTS_VALU"], "avg_us": round(avg_s * 1e6, 2),
+                   "peak_note": "1024 SIMDs x 2.4 GHz / 2 cycles per cheap wave64 instruction; under this load the part runs at 1.9-2.2 GHz",
+                   "source": sq_file + ", profiles/r04_valu_issue_costs.txt"}
+            if "SQ_INSTS_VALU_FMA_F32" in c:
+                f32 = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_FMA_F32"]
+                i32, i64, cvt, trans = c["SQ_INSTS_VALU_INT32"], c.get("SQ_INSTS_VALU_INT64", 0.0), c["SQ_INSTS_VALU_CVT"], c["SQ_INSTS_VALU_TRANS_F32"]
+                rest = max(c["SQ_INSTS_VALU"] - f32 - i32 - i64 - cvt - trans, 0.0)          # moves, compares, selects, lane ops, ...
+                lo = 2 * f32 + 2 * i32 + 4 * i64 + 4 * cvt + 8 * trans + 2 * rest
+                hi = 2 * f32 + 4 * i32 + 4 * i64 + 4 * cvt + 8 * trans + 4 * rest
+                out["class_mix"] = {"f32_add_mul_fma": f32, "int32": i32, "int64": i64, "cvt": cvt, "transcendental": trans, "other": rest}
+                if "GRBM_GUI_ACTIVE" in c and c.get("GRBM_duration_us"):
+                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the counter pass runs every kernel alone (serialised launches), so
+                    # the busy share is taken against that pass's own cycles, not against the live duration
+                    xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+                    out["pipe_busy"] = {"low": round(lo / (1024 * xcd_cycles), 3), "high": round(hi / (1024 * xcd_cycles), 3),
+                                        "of": "the counter pass's launch (kernel alone)", "duration_us": c["GRBM_duration_us"],
+                                        "clock_ghz": round(xcd_cycles / c["GRBM_duration_us"] / 1e3, 2)}
+            return out
 
         def roof_l1(name):
             """The tile pass's other bound: the L1's tag look-ups (one cache line per clock per CU).  achieved = look-ups per
@@ -744,12 +762,22 @@ def main():
         # bytes the tile pass really writes per pixel: 28, or 20 while the library knows the emissive plane is all zero and does not
         # rewrite it (VR_OPT_PLANE_TRACKING: main_ps's o_channel3 = 0 lands on zeros)
         emissive_skipped = bool(rt.plane_known_zero("emissive"))
-        raster_bytes = GBUFFER_BYTES_PER_PX - (8 if emissive_skipped else 0)
+        plane_bytes = GBUFFER_BYTES_PER_PX - (8 if emissive_skipped else 0)
+        # ... and per region (8 rows x 32 pixels): a sky region known clear is not written, a terrain region known to hold the
+        # shader's specular constant keeps that plane.  The states after the last frame say what a frame of this flythrough skips
+        # (consecutive views differ little); the HBM-side truth is WRITE_SIZE in `traffic`.
+        census = rt.region_census()
+        f_clear = census["clear"] / max(census["total"], 1)
+        f_spec = census["specular_constant"] / max(census["total"], 1)
+        raster_bytes = round(plane_bytes * (1.0 - f_clear) - 4.0 * f_spec, 2)
         roof_raster = roof("k_raster", raster_bytes, owned_px)
         if roof_raster:
             roof_raster["bytes_per_pixel"] = raster_bytes
             roof_raster["emissive_plane"] = ("known zero (cleared at creation, only zeros written since): not rewritten, 20 of the G-buffer's 28 B/px leave the pass"
                                              if emissive_skipped else "written")
+            roof_raster["regions"] = dict(census, note="8x32-pixel regions by what the library knows they hold after the last frame: `clear` regions "
+                                          "(sky) were not written, `specular_constant` regions (terrain) kept their specular plane (4 B/px); "
+                                          "bytes_per_pixel = the frame's average over all pixels")
         if roof_raster:
             # the tile pass only writes: what a store-only kernel of its own pattern reaches on this part (tools/micro/fill_rate.hip:
             # 929 MB in 156-163 us), next to the 8 TB/s of reads and writes together that `peak` is

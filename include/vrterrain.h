@@ -288,6 +288,13 @@ VR_API int  vr_gbuffer_clear(vr_gbuffer* gb);
 VR_API int  vr_gbuffer_describe(vr_gbuffer* gb, vr_gbuffer_desc* out);
 /* 1 when the library knows `plane` (4 = emissive; others: 0) holds only zeros and the next tile pass will not rewrite it. */
 VR_API int  vr_gbuffer_plane_known_zero(vr_gbuffer* gb, int plane);
+/* Plane-state tracking per region (VR_OPT_PLANE_TRACKING; a region = 8 rows x 32 pixels, what one wave of a 32-pixel raster
+ * tile resolves): counts[0] regions nothing is known about, counts[1] regions whose specular plane holds the terrain
+ * shader's one constant in every pixel (terrain_ps.hlsl:76: the next tile pass that covers such a region completely does not
+ * rewrite that plane), counts[2] regions that hold the clear values in all planes (a tile pass over a cleared target that
+ * draws nothing there writes nothing), counts[3] their total.  The planes' contents never depend on the tracking; this is
+ * what a bench needs to say how many bytes a tile pass really wrote.  Waits for the context's stream. */
+VR_API int  vr_gbuffer_region_census(vr_gbuffer* gb, uint32_t counts[4]);
 /* test/IO helpers: copy planes host<->device (synchronous). plane: 0 depth,
  * 1 diffuse, 2 specular, 3 normals, 4 emissive. */
 VR_API int  vr_gbuffer_download(vr_gbuffer* gb, int plane, void* host, size_t bytes);

@@ -1154,6 +1154,95 @@ def test_context_stream_changed_between_prepare_and_render(scene2048, oracle, gp
         rt.close()
 
 
+def test_region_tracking_never_changes_the_gbuffer(scene256, oracle, gpu_ctx):
+    """VR_OPT_PLANE_TRACKING per region (8 rows x 32 pixels): a sky region known to hold the clear values is not written by a
+    pass over a 'cleared' target, a terrain region known to hold the specular constant keeps that plane.  Through a history of
+    moving cameras (sky <-> terrain), clears, foreign writes, keep-what-is-there passes, other variants of the tile pass
+    (wireframe, depth only, 64-pixel tiles, a partition) the five planes equal the oracle's after every step, with the tracking
+    on and off; the census shows that regions really were skipped."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 544, 300                                            # partial tiles on both edges
+    cams = [scaled_camera(c, 256) for c in (CAMERAS[0], CAMERAS[5], CAMERAS[7], CAMERAS[1])]
+    cams.append(((10.0, 60.0, 10.0), (60.0, 200.0, 60.0)))     # looking up: sky only
+    views = [vr.make_view(e, t, w, h) for e, t in cams]
+    rp_c, rp_k = vr.default_render_params(400.0, assume_cleared=1), vr.default_render_params(400.0)
+    rng = np.random.default_rng(5)
+    junk32 = rng.integers(1, 2 ** 32 - 1, (h, w), dtype=np.uint32)
+    names = ("depth", "diffuse", "specular", "normals", "emissive")
+
+    def planes(rt):
+        return {k: rt.download(k) for k in names}
+    saw_clear = saw_spec = False
+    for tracking in (True, False):
+        gpu_ctx.set_plane_tracking(tracking)
+        rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+        cur = [oracle.GBufferHost(w, h)]
+
+        def over_cleared(i, part=None, what=""):
+            cur[0] = oracle.GBufferHost(w, h) if part is None else cur[0]
+            if part is None:
+                ot.render(views[i], cur[0], rp_k)
+            tp.Render(views[i], views[i], rt, rp_c, part)
+            if part is None:
+                _assert_gbuffer_equal(cur[0], planes(rt), f"{what} view {i} over a 'cleared' target (tracking {tracking})")
+
+        def keep(i, what=""):
+            ot.render(views[i], cur[0], rp_k)
+            tp.Render(views[i], views[i], rt, rp_k)
+            _assert_gbuffer_equal(cur[0], planes(rt), f"{what} view {i} over what is there (tracking {tracking})")
+        try:
+            c = rt.region_census()
+            assert c["total"] == 4 * ((w + 31) // 32) * ((h + 31) // 32)
+            assert c["clear"] == (c["total"] if tracking else 0)              # created cleared
+            for i in (0, 0, 1, 4, 4, 2, 3, 0, 4, 1):
+                over_cleared(i)
+                c = rt.region_census()
+                assert c["unknown"] + c["specular_constant"] + c["clear"] == c["total"]
+                if tracking:
+                    saw_clear |= c["clear"] > 0
+                    saw_spec |= c["specular_constant"] > 0
+                    if i == 4:
+                        assert c["clear"] == c["total"], "a sky-only frame leaves every region clear"
+                else:
+                    assert c["unknown"] == c["total"]
+            # foreign writes
+            rt.upload("specular", junk32)
+            assert rt.region_census()["unknown"] == rt.region_census()["total"]
+            over_cleared(0, what="after a foreign write to the specular plane:")
+            over_cleared(0)
+            rt.upload("depth", junk32.view(np.float32))
+            over_cleared(4, what="after a foreign write to the depth plane:")
+            # clear, then keep-what-is-there passes (two views composed by the depth test)
+            rt.Clear(); cur[0] = oracle.GBufferHost(w, h)
+            keep(1); keep(0); keep(0); keep(4)
+            over_cleared(0); keep(1, what="over a tracked frame:"); over_cleared(1)
+            # other variants of the tile pass in between: they write planes without keeping the states
+            over_cleared(0)
+            tp.Render(views[1], views[1], rt, vr.default_render_params(400.0, assume_cleared=1, wireframe=1))
+            over_cleared(0, what="after a wireframe pass:")
+            tp.Render(views[4], views[4], rt, vr.default_render_params(400.0, assume_cleared=1, depth_only=1))
+            over_cleared(0, what="after a depth-only pass:")
+            gpu_ctx.set_raster_tile(64)
+            over_cleared(1, what="64-pixel tiles:"); over_cleared(1, what="64-pixel tiles:")
+            gpu_ctx.set_raster_tile(0)
+            over_cleared(1, what="back on 32-pixel tiles:"); over_cleared(0)
+            # a partition writes its own tiles only: the other tiles' states stay valid for what they hold
+            over_cleared(1)
+            over_cleared(0, vr.Partition(1, 2))
+            got = planes(rt)
+            ty, tx = np.indices((h, w))
+            owned = ((tx // 128 + ty // 128) % 2) == 1
+            want0 = oracle.GBufferHost(w, h); ot.render(views[0], want0, rp_k)
+            for k in names:
+                assert np.array_equal(got[k][owned], getattr(want0, k)[owned]) and np.array_equal(got[k][~owned], getattr(cur[0], k)[~owned]), k
+            over_cleared(0, what="after a partitioned pass:"); over_cleared(4); over_cleared(0)
+        finally:
+            gpu_ctx.set_raster_tile(0)
+            gpu_ctx.set_plane_tracking(True)
+            rt.close()
+    assert saw_clear and saw_spec
+
+
 def test_emissive_plane_tracking_never_changes_the_gbuffer(scene256, oracle, gpu_ctx):
     """VR_OPT_PLANE_TRACKING: main_ps writes 0 to the emissive target (terrain_ps.hlsl:80) and Clear writes 0, so the tile pass
     skips the plane while the library knows it is all zero.  Whatever the history - fresh target, foreign writes (upload),

@@ -1,6 +1,8 @@
 #!/bin/bash
 # On the GPU box: rocprofv3 kernel statistics and PMC passes of the bench commands, into gpurun_out/prof_$TAG/.
 # usage: tools/collect_profiles.sh TAG [what...]   what = stats pmc sq (default: all)
+# afterwards (here): python tools/summarize_pmc.py traffic pmc_fetch_8k.csv pmc_write_8k.csv profiles/rNN_pmc_traffic.json
+#                    python tools/summarize_pmc.py sq pmc_sqa_8k.csv pmc_sqb_8k.csv pmc_sqc_8k.csv pmc_sqd_8k.csv profiles/rNN_pmc_sq.json
 set -e
 TAG=$1; shift
 WHAT=${@:-stats pmc sq}
@@ -35,6 +37,8 @@ pmc)
 sq)
   run_pmc sqa_8k SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --
   run_pmc sqb_8k SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --
+  run_pmc sqc_8k SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM --
+  run_pmc sqd_8k GRBM_GUI_ACTIVE --
   run_pmc sqa_8k_lights1024 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- --lights 1024
   run_pmc sqb_8k_lights1024 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- --lights 1024 ;;
 esac; done

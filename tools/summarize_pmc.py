@@ -1,7 +1,7 @@
 """Turns the rocprofv3 PMC passes collected by tools/collect_profiles.sh into the JSON files bench.py reads.
 
   python tools/summarize_pmc.py traffic FETCH.csv WRITE.csv OUT.json     # HBM bytes per launch (roofline.traffic)
-  python tools/summarize_pmc.py sq SQA.csv SQB.csv OUT.json             # SQ counters per launch (roofline_valu)
+  python tools/summarize_pmc.py sq SQA.csv SQB.csv [SQC.csv ...] OUT.json   # SQ / GRBM counters per launch (roofline_valu)
 
 Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for the lighting passes
@@ -20,12 +20,17 @@ def agg(path):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if k.startswith("k_"):
             d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":     # the launch's duration in the same pass: cycles / time = the clock it ran at
+                d[k]["GRBM_duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in d.items()}
 
 
 def main():
-    mode, a, b, out_path = sys.argv[1:5]
+    mode, a, b, out_path = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[-1]
     A, B = agg(a), agg(b)
+    for extra in sys.argv[4:-1]:                      # further SQ passes (instruction classes, GRBM_GUI_ACTIVE): merged into B
+        for k, cs in agg(extra).items():
+            B.setdefault(k, {}).update(cs)
     out = {}
     if mode == "traffic":
         for k in sorted(set(A) | set(B)):

@@ -147,7 +147,7 @@ EXPORTS = [
     "vr_last_error", "vr_version", "vr_build_experiments", "vr_timing_enable", "vr_timing_collect", "vr_timing_kernel_count", "vr_kernel_name", "vr_view_from_camera", "vr_terrain_default_params",
     "vr_render_default_params", "vr_terrain_create", "vr_terrain_destroy", "vr_terrain_num_lods",
     "vr_terrain_lod_ranges", "vr_terrain_download_mip", "vr_terrain_update_heights", "vr_terrain_download_node_heights", "vr_terrain_select", "vr_terrain_render", "vr_terrain_render_lit", "vr_terrain_prepare", "vr_terrain_num_chunks",
-    "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe", "vr_gbuffer_plane_known_zero",
+    "vr_gbuffer_create", "vr_gbuffer_destroy", "vr_gbuffer_clear", "vr_gbuffer_describe", "vr_gbuffer_plane_known_zero", "vr_gbuffer_region_census",
     "vr_gbuffer_download", "vr_gbuffer_upload", "vr_image_create", "vr_image_destroy",
     "vr_image_device_ptr", "vr_image_download", "vr_image_upload", "vr_ldr_image_create", "vr_ldr_image_destroy", "vr_ldr_image_device_ptr", "vr_ldr_image_capacity", "vr_ldr_image_download", "vr_ldr_image_upload", "vr_deferred_light", "vr_deferred_light_tiled", "vr_deferred_tiled_status", "vr_partition_num_tiles",
     "vr_partition_packed_bytes", "vr_partition_prepare", "vr_frame_detile",
@@ -214,6 +214,7 @@ def load_library():
         "vr_gbuffer_clear": (C.c_int, [vp]),
         "vr_gbuffer_describe": (C.c_int, [vp, P(GBufferDesc)]),
         "vr_gbuffer_plane_known_zero": (C.c_int, [vp, C.c_int]),
+        "vr_gbuffer_region_census": (C.c_int, [vp, vp]),
         "vr_gbuffer_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "vr_gbuffer_upload": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "vr_image_create": (C.c_int, [vp, C.c_int32, C.c_int32, vp, P(vp)]),

@@ -426,6 +426,7 @@ extern "C" VR_API void vr_gbuffer_destroy(vr_gbuffer* g)
     (void)hipSetDevice(g->ctx->device);
     (void)hipFree(g->depth);   // base of the single allocation
     (void)hipFree(g->d_ranges);
+    (void)hipFree(g->d_region);
     delete g;
 }
 
@@ -468,6 +469,39 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
     if ((rc = fill_u32(s, g->normals, n * 2, 0u))) return rc;
     if ((rc = fill_u32(s, g->emissive, n * 2, 0u))) return rc;
     g->emissive_zero = true;               // (stream-ordered: every later pass on the context's stream sees the zeros)
+    g->region_fill = (int)kRegionClear;    // every region holds the clear values (the array is filled when a tile pass next asks for it)
+    return VR_OK;
+}
+
+int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out)
+{
+    const int tiles = ((g->w + 31) / 32) * ((g->h + 31) / 32);
+    if (!g->d_region) {
+        VR_HIP(hipMalloc(&g->d_region, (size_t)tiles * 4));
+        g->region_tiles = tiles;
+        if (g->region_fill < 0) g->region_fill = 0;
+    }
+    if (g->region_fill >= 0) {
+        VR_HIP(hipMemsetAsync(g->d_region, g->region_fill, (size_t)tiles * 4, s));
+        g->region_fill = -1;
+    }
+    *out = g->d_region;
+    return VR_OK;
+}
+
+extern "C" VR_API int vr_gbuffer_region_census(vr_gbuffer* g, uint32_t counts[4])
+{
+    VR_REQUIRE(g && counts, "NULL argument");
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    const int tiles = ((g->w + 31) / 32) * ((g->h + 31) / 32);
+    counts[3] = (uint32_t)tiles * 4u;
+    if (!g->ctx->plane_tracking || g->escaped) { counts[0] = counts[3]; return VR_OK; }      // no region is known to hold anything
+    if (!g->d_region || g->region_fill >= 0) { counts[g->region_fill == (int)kRegionClear ? 2 : 0] = counts[3]; return VR_OK; }
+    VR_HIP(hipSetDevice(g->ctx->device));
+    std::vector<uint8_t> h((size_t)tiles * 4);
+    VR_HIP(hipMemcpyAsync(h.data(), g->d_region, h.size(), hipMemcpyDeviceToHost, g->ctx->stream));
+    VR_HIP(hipStreamSynchronize(g->ctx->stream));
+    for (uint8_t b : h) counts[b <= 2 ? b : 0]++;
     return VR_OK;
 }
 
@@ -504,6 +538,7 @@ extern "C" VR_API int vr_gbuffer_describe(vr_gbuffer* g, vr_gbuffer_desc* d)
     vr_gbuffer_touch(g);           // the caller gets the device pointers: whatever it writes through them is unknown here,
     g->escaped = true;             // now and for as long as the G-buffer lives (no depth ranges, no plane-state tracking any more)
     g->emissive_zero = false;
+    g->region_fill = 0;
     d->width = g->w; d->height = g->h; d->depth = g->depth; d->diffuse = g->diffuse; d->specular = g->specular;
     d->normals = g->normals; d->emissive = g->emissive;
     return VR_OK;
@@ -540,6 +575,7 @@ extern "C" VR_API int vr_gbuffer_upload(vr_gbuffer* g, int plane, const void* ho
     VR_HIP(hipSetDevice(g->ctx->device));
     vr_gbuffer_touch(g);
     if (plane == 4) g->emissive_zero = false;
+    g->region_fill = 0;                    // (no region is known clear - that includes the emissive plane - or constant any more)
     VR_HIP(hipMemcpyAsync(p, host, nb, hipMemcpyHostToDevice, g->ctx->stream));
     VR_HIP(hipStreamSynchronize(g->ctx->stream));
     return VR_OK;

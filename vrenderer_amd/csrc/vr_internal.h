@@ -225,7 +225,18 @@ struct vr_gbuffer {
     // tiles' depth ranges above).
     bool emissive_zero = false;
     bool escaped = false;
+    // The same idea per REGION (the 8 rows x 32 pixels one wave of a 32-pixel raster tile resolves), one byte each, kept on the
+    // device by the fast variant of the tile pass: kRegionClear = every pixel holds the clear values in all planes (RenderTargets::
+    // Clear, or a pass over a cleared target that drew nothing there); kRegionSpec = every pixel holds the pass's one specular
+    // constant (terrain_ps.hlsl:76).  A sky region that is known clear is not written again and a terrain region keeps its
+    // specular plane - the planes' contents are what they would be anyway.  region_fill: -1 = the device array is current,
+    // else the byte it has to be filled with before its next use (0 after anything foreign wrote a plane, kRegionClear after a clear).
+    uint8_t* d_region = nullptr;
+    int region_tiles = 0;
+    int region_fill = 0;
 };
+constexpr uint32_t kRegionSpec = 1u, kRegionClear = 2u;
+int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out);     // allocated and current (vr_host.hip)
 // (anything else that writes the G-buffer: its depth ranges are stale)
 inline void vr_gbuffer_touch(vr_gbuffer* g) { if (g->ranges_state == vr_gbuffer::RANGES_VALID) g->ranges_state = vr_gbuffer::RANGES_DIRTY; }
 int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s);      // allocated and every entry "none" (vr_host.hip)

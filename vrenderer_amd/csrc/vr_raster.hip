@@ -1252,8 +1252,15 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
                                                  uint2* __restrict__ g_nrm, uint2* __restrict__ g_emi,
                                                  const float* __restrict__ thr_g,
                                                  const uint8_t* __restrict__ enc_g, uint32_t spec_const, uint2* __restrict__ ranges,
+                                                 uint8_t* __restrict__ region,
                                                  typename std::conditional<LIT, LitArgs, LitNone>::type lit)
 {
+    // Region states (plane-state tracking, vr_gbuffer::d_region; NULL: off): one byte per wave of a 32-pixel tile = its 8 rows x 32
+    // pixels.  kRegionClear: every pixel of the region holds the clear values in all planes; kRegionSpec: every pixel holds
+    // spec_const in the specular plane (main_ps writes one constant there, terrain_ps.hlsl:76).  A region that is all sky and
+    // known clear is not written at all, a region that is all terrain and known constant keeps its specular plane: the bytes in
+    // memory are the same either way.
+    constexpr bool TRACK = MODE == RM_FAST && TILE == 32 && !LIT && !WIRE;
     static_assert(!LIT || (MODE == RM_FAST && !RANGES), "the fused variant is the fast variant");
     static_assert((!RANGES && !NOEMI) || MODE == RM_FAST, "depth ranges and the emissive skip come with the fast variant");
     __shared__ unsigned long long vis[TILE * TILE];
@@ -1288,6 +1295,11 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
     const uint32_t off = tile_offset[tile], n_all = tile_cursor[tile] - off;     // bin = entries[off .. off + n_all)
     const uint32_t n = min(n_all, off < a.bin_capacity ? a.bin_capacity - off : 0u);   // (an overflowing frame drops the entries beyond the capacity: VR_ERR_OVERFLOW)
     const TileEntry* __restrict__ bin = entries + off;
+    if constexpr (TRACK) {
+        // nothing to draw and the whole tile known to hold the clear values already: done (workgroup-uniform)
+        if (region != nullptr && a.assume_cleared && n_all == 0u
+            && reinterpret_cast<const uint32_t*>(region)[tile] == kRegionClear * 0x01010101u) return;
+    }
     const bool lds_recs = !WIRE && MODE != RM_DEPTH && n <= (uint32_t)kSparseMax;      // (workgroup-uniform)
     uint4 rec_r = make_uint4(0, 0, 0, 0);                         // requested now, stored behind the sweeps: its latency is theirs
     if (lds_recs && (uint32_t)tid < n * 3u) {
@@ -1566,7 +1578,29 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
     else { nrec.g5 = (u32x4){ 0u, 0u, 0u, 0u }; nrec.g6 = (u3){ 0u, 0u, 0u }; nrec.g7 = nrec.g6; }
     // RANGES: smallest / largest depth bits below 1.0 this lane has seen in the upper / lower 32 rows of the tile
     uint32_t rmin0 = 0x7f800000u, rmax0 = 0u, rmin1 = 0x7f800000u, rmax1 = 0u;
-    for (int g = tid; g < kStrips; g += kRT) {
+    bool skip_all = false, skip_spec = false;                     // (wave-uniform)
+    if constexpr (TRACK) {
+        if (region != nullptr) {
+            const uint32_t ri = (uint32_t)tile * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+            const uint32_t st = region[ri];
+            // this lane's four pixels (those that lie on the target): all covered / none covered
+            const int lx = tid % TILE, ly0 = (tid / TILE) * 4;
+            bool c_all = true, c_none = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool on = whole || (ox + lx < a.w && oy + ly0 + k < a.h);
+                const bool cov = (uint32_t)nkeys[k] != 0xffffffffu;
+                c_all = c_all && (!on || cov); c_none = c_none && (!on || !cov);
+            }
+            const bool all_cov = __all(c_all), none_cov = __all(c_none);
+            uint32_t nst;
+            if (none_cov) { skip_all = a.assume_cleared ? st == kRegionClear : true; nst = a.assume_cleared ? kRegionClear : st; }
+            else if (all_cov) { skip_spec = st == kRegionSpec; nst = kRegionSpec; }
+            else nst = (!a.assume_cleared && st == kRegionSpec) ? kRegionSpec : 0u;
+            if (nst != st && lane == 0) region[ri] = (uint8_t)nst;
+        }
+    }
+    for (int g = skip_all ? kStrips : tid; g < kStrips; g += kRT) {
         const int lx = g % TILE, ly0 = (g / TILE) * 4;
         const int gx = ox + lx, gy0 = oy + ly0;
         const unsigned long long keys[4] = { nkeys[0], nkeys[1], nkeys[2], nkeys[3] };
@@ -1658,7 +1692,7 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
                 if (!depth_only) {
                     const uint32_t pix8 = pix4 + pix4;
                     __builtin_amdgcn_raw_buffer_store_b32(dif, rgb, pix4, o_diff, aux);
-                    __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
+                    if (!skip_spec) __builtin_amdgcn_raw_buffer_store_b32(cov ? spec_const : 0u, rgb, pix4, o_spec, aux);
                     const u2 nv = { nn0, nn1 }, zv = { 0u, 0u };
                     __builtin_amdgcn_raw_buffer_store_b64(nv, rgb, pix8, o_nrm, aux);
                     if (!NOEMI && !kExpNoEmissive) __builtin_amdgcn_raw_buffer_store_b64(zv, rgb, pix8, o_emi, aux);
@@ -2014,9 +2048,13 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
             }
         }
         if (lit_done) *lit_done = fuse;
+        // region states: kept by the fast variant on 32-pixel tiles; any other variant writes the planes without keeping them
+        uint8_t* region = nullptr;
+        if (fast && !fuse && a.tile_shift == 5 && ctx->plane_tracking && !gb->escaped) { if ((rc = vr_gbuffer_region_prepare(gb, s, &region))) return rc; }
+        else gb->region_fill = 0;
 #define VR_RASTER_ARGS a, t->height, t->albedo, g.d_verts, g.d_hard_tris, g.d_hard_first, \
                            (const uint4*)g.d_recs, (uint32_t)t->cap_instances * (uint32_t)kTrisPerInst, g.d_tile_cursor, g.d_tile_offset, g.d_bin_entries, tiles, g.d_counters + C_CLASS0, \
-                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr
+                           gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, ctx->d_srgb_thr, ctx->d_enc_tab, spec_const, ranges ? gb->d_ranges : (uint2*)nullptr, region
         if (fuse) {
             ks.id = VR_K_RASTER_LIT;
             if (a.tile_shift == 5) VR_LAUNCH_TIMED(ks, (k_raster<false, 32, RM_FAST, false, true, true>), dim3(grid), dim3(kRT), s, VR_RASTER_ARGS, la);

@@ -169,6 +169,12 @@ class RenderTargets:
         """True when the next tile pass will not rewrite `plane` because the library knows it holds only zeros."""
         return bool(self.ctx.lib.vr_gbuffer_plane_known_zero(self.handle, self.PLANES[plane][0]))
 
+    def region_census(self):
+        """Plane-state tracking per 8x32-pixel region: dict(unknown, specular_constant, clear, total); synchronises."""
+        c = (C.c_uint32 * 4)()
+        check(self.ctx.lib.vr_gbuffer_region_census(self.handle, c), "vr_gbuffer_region_census")
+        return dict(unknown=c[0], specular_constant=c[1], clear=c[2], total=c[3])
+
     def describe(self):
         d = GBufferDesc()
         check(self.ctx.lib.vr_gbuffer_describe(self.handle, C.byref(d)), "vr_gbuffer_describe")
