@@ -574,6 +574,37 @@ def main():
         sustained = {"value": round(W * H * args.steps / el2 / 1e9, 3), "unit": "Gpixels/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
                      "what": f"the same {args.steps} steps timed again behind one further lap (120 frames) of load, when the device has returned to its "
                              "sustained clocks after the idle set-up phase (round 3's `value` was measured like this: its bench rendered an untimed lap first)"}
+    # ... and once more with the plane-state tracking off (VR_OPT_PLANE_TRACKING = 0): every tile pass writes all five planes of
+    # every pixel and the lighting pass reads them all, as a renderer without clear / constant metadata would.  Same frames, same
+    # bits in the G-buffer and in HdrColor; reported beside `value` so that the tracking's share of it is on the page.
+    untracked = None
+    if not args.no_sustained and not args.fused:
+        ctx.set_plane_tracking(False)
+        gc.collect(); gc.disable()
+        for i in range(20):
+            step(args.warmup + i)
+        sync()
+        ctx.timing_enable(2)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + args.steps + 120 + i)
+        gc.enable()
+        sync()
+        el3 = time.perf_counter() - t1
+        t_off = ctx.timing_collect()
+        ctx.timing_enable(False)
+        ctx.set_plane_tracking(True)
+        if use_dist:
+            t3 = torch.tensor([el3], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            el3 = float(t3.item())
+        untracked = {"value": round(W * H * args.steps / el3 / 1e9, 3), "unit": "Gpixels/s", "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                     "kernels": {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in t_off.items()},
+                     "what": f"the same {args.steps} steps as `sustained` with vr_context_set_option(VR_OPT_PLANE_TRACKING, 0): 28 B/px written by "
+                             "the tile pass and 28 B/px read by the lighting pass whatever the planes hold"}
+        for i in range(3):                   # (back on: the states are rebuilt by the next frames)
+            step(args.warmup + i)
+        sync()
     kernels_note = None
     if timing_level == 2:
         # the small kernels (geometry chain, tone-map stage, de-tile), timed with events around every launch over a few
@@ -679,22 +710,30 @@ def main():
             except Exception:
                 sq = {}
 
-        def roof(name, bytes_per_px, px):
+        def roof(name, bytes_per_px, px, moved_per_px=None, moved_note=None):
+            """achieved = ALGORITHMIC bytes per launch (SURVEY 8d's per-pixel figure x the launch's pixels) / the launch's HIP-event
+            duration.  With the plane-state tracking on, the launch MOVES fewer bytes than that (it does not rewrite / re-read what
+            the library knows the planes hold): `moved` has that figure and the rate it corresponds to."""
             if name not in timings:
                 return None
             ms, n = timings[name]
             avg_s = ms / n * 1e-3
             ach = bytes_per_px * px / avg_s / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
-                    "traffic_source": (pmc_file + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                                  "not measured in this run)") if name in pmc else None,
-                    "avg_us": round(avg_s * 1e6, 2), "bytes_per_launch": bytes_per_px * px,
-                    "note": f"{bytes_per_px} algorithmic B/pixel x {px} pixels per launch / HIP-event duration"
-                            + ("; a kernel that only moves the same bytes reaches 5.6-5.9 TB/s on this part (profiles/r01_stream_layout_ceiling.txt)"
-                               if name == "k_deferred" else "; runs at ~80 % of the per-CU memory pipeline (fetches and stores in series) and at half of a store-only kernel's rate, "
-                                    "see write_stream_ceiling, roofline_l1, roofline_valu and DESIGN.md 4")}
+            out = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(ach / HBM_PEAK_GBS, 4),
+                   "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
+                   "traffic_source": (pmc_file + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                                 "not measured in this run)") if name in pmc else None,
+                   "avg_us": round(avg_s * 1e6, 2), "bytes_per_launch": bytes_per_px * px,
+                   "note": f"{bytes_per_px} algorithmic B/pixel (SURVEY 8d) x {px} pixels per launch / HIP-event duration"
+                           + ("; a kernel that only moves the same bytes reaches 5.6-5.9 TB/s on this part (profiles/r01_stream_layout_ceiling.txt)"
+                              if name == "k_deferred" else "; runs at ~80 % of the per-CU memory pipeline (fetches and stores in series) and at half of a store-only kernel's rate, "
+                                   "see write_stream_ceiling, roofline_l1, roofline_valu and DESIGN.md 4")}
+            if moved_per_px is not None:
+                mv = moved_per_px * px / avg_s / 1e9
+                out["moved"] = {"bytes_per_pixel": moved_per_px, "bytes_per_launch": round(moved_per_px * px), "achieved": round(mv, 1),
+                                "frac": round(mv / HBM_PEAK_GBS, 4), "note": moved_note}
+            return out
 
         def roof_valu(name):
             """Vector-instruction issue of the tile pass / the tiled lighting pass.  achieved = wave-instructions per launch
@@ -753,7 +792,18 @@ def main():
                     "frac": round(ach / peak, 4), "lookups_per_launch": tcp[name]["TCP_TOTAL_CACHE_ACCESSES"],
                     "pending_stall_cycles_per_launch": tcp[name]["TCP_PENDING_STALL_CYCLES"], "source": tcp_file}
 
-        roof_deferred = roof(light_kernel, DEFERRED_BYTES_PER_PX, owned_px)
+        # bytes the lighting pass really moves per pixel: 8 written; read 28, less the emissive plane (8) while it is known zero,
+        # less the specular plane (4) in regions known to hold the shader's constant, nothing in regions known clear (sky)
+        census_l = rt.region_census()
+        emi_zero = bool(rt.plane_known_zero("emissive"))
+        fl_clear = census_l["clear"] / max(census_l["total"], 1)
+        fl_spec = census_l["specular_constant"] / max(census_l["total"], 1)
+        read_px = (28 - (8 if emi_zero else 0)) * (1.0 - fl_clear) - 4.0 * fl_spec
+        deferred_moved = round(8 + read_px, 2) if (light_kernel == "k_deferred") else None
+        roof_deferred = roof(light_kernel, DEFERRED_BYTES_PER_PX, owned_px, deferred_moved,
+                             "8 B/px written; of the G-buffer's 28 B/px the pass reads what the plane-state tracking does not already know: no emissive "
+                             "plane while it is zero, no specular plane in regions that hold the shader's constant, nothing in regions that are "
+                             "clear (region states after the last frame; `traffic` is the HBM-side measurement)")
         if tiled and roof_deferred and "k_light_cull" in timings:      # config 5's lighting is two launches: price the pair
             pair_s = (timings[light_kernel][0] / timings[light_kernel][1] + timings["k_light_cull"][0] / timings["k_light_cull"][1]) * 1e-3
             ach = DEFERRED_BYTES_PER_PX * owned_px / pair_s / 1e9
@@ -769,19 +819,18 @@ def main():
         census = rt.region_census()
         f_clear = census["clear"] / max(census["total"], 1)
         f_spec = census["specular_constant"] / max(census["total"], 1)
-        raster_bytes = round(plane_bytes * (1.0 - f_clear) - 4.0 * f_spec, 2)
-        roof_raster = roof("k_raster", raster_bytes, owned_px)
+        raster_moved = round(plane_bytes * (1.0 - f_clear) - 4.0 * f_spec, 2)
+        roof_raster = roof("k_raster", GBUFFER_BYTES_PER_PX, owned_px, raster_moved,
+                           "the frame's average over all pixels: 28 B/px less the emissive plane (8) while it is known zero, less the specular plane (4) "
+                           "in regions known to hold the shader's constant, nothing in regions known clear")
         if roof_raster:
-            roof_raster["bytes_per_pixel"] = raster_bytes
-            roof_raster["emissive_plane"] = ("known zero (cleared at creation, only zeros written since): not rewritten, 20 of the G-buffer's 28 B/px leave the pass"
-                                             if emissive_skipped else "written")
+            roof_raster["emissive_plane"] = ("known zero (cleared at creation, only zeros written since): not rewritten" if emissive_skipped else "written")
             roof_raster["regions"] = dict(census, note="8x32-pixel regions by what the library knows they hold after the last frame: `clear` regions "
-                                          "(sky) were not written, `specular_constant` regions (terrain) kept their specular plane (4 B/px); "
-                                          "bytes_per_pixel = the frame's average over all pixels")
+                                          "(sky) were not written, `specular_constant` regions (terrain) kept their specular plane")
         if roof_raster:
             # the tile pass only writes: what a store-only kernel of its own pattern reaches on this part (tools/micro/fill_rate.hip:
             # 929 MB in 156-163 us), next to the 8 TB/s of reads and writes together that `peak` is
-            roof_raster["write_stream_ceiling"] = {"gbs": WRITE_STREAM_GBS, "frac": round(roof_raster["achieved"] / WRITE_STREAM_GBS, 4),
+            roof_raster["write_stream_ceiling"] = {"gbs": WRITE_STREAM_GBS, "frac": round(roof_raster["moved"]["achieved"] / WRITE_STREAM_GBS, 4),
                                                    "source": "profiles/r03_fill_rate.txt (measured, not a datasheet figure)"}
         out = {
             "metric": "shaded Gpixels/s at 8K terrain", "value": round(value, 3), "unit": "Gpixels/s",
@@ -791,6 +840,7 @@ def main():
                               "needs ~15 ms of load after the host-side set-up to reach its sustained clocks (same 20 frames: 0.585 ms straight "
                               "after 5 warm-up frames, 0.549 ms after a lap; --prewarm-laps 0 for the raw figure)") if args.prewarm_laps else None,
             "sustained": sustained,
+            "without_plane_tracking": untracked,
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    + (f"1 sun + {args.lights - 1} point lights (seed 9001, range 20-80) through the tiled pass; " if tiled
                                       else "1 directional light; ")

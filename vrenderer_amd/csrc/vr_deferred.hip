@@ -60,14 +60,12 @@ __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArg
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
                                                    const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
                                                    uint2* __restrict__ out, const float* __restrict__ lut_g,
-                                                   const int32_t* __restrict__ owned_tiles, ShadowArgs sh)
+                                                   const int32_t* __restrict__ owned_tiles, ShadowArgs sh, PlaneHints hints)
 {
     __shared__ float lut[256];
-    lut[threadIdx.x] = lut_g[threadIdx.x];
-    __syncthreads();
-
     int px0, py;          // first pixel of this lane's quad
     size_t out_index;     // in pixels
+    bool valid;
     if (PACKED) {
         const int lt = blockIdx.x >> 4, rg = blockIdx.x & 15;
         const int tile = owned_tiles[lt];
@@ -75,30 +73,58 @@ __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArg
         const int row = rg * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 4;
         px0 = tx * VR_OWNER_TILE + col; py = ty * VR_OWNER_TILE + row;
         out_index = ((size_t)lt * VR_OWNER_TILE + row) * VR_OWNER_TILE + col;
-        if (px0 >= a.w || py >= a.h) return;
+        valid = px0 < a.w && py < a.h;
     } else {
         const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
         const size_t p = q * 4;
-        if (p >= (size_t)a.w * a.h) return;
+        valid = p < (size_t)a.w * a.h;
         py = (int)(p / (size_t)a.w); px0 = (int)(p - (size_t)py * a.w);
         out_index = p;
     }
     const size_t p = (size_t)py * a.w + px0;
-    // issue every load first: 7 x 16 B per lane in flight
+    // What the library knows about the planes (plane-state tracking, vr_gbuffer): a region - 8 rows x 32 pixels, this quad lies
+    // in one - that holds the clear values is not read at all, one that holds the terrain shader's specular constant in every
+    // pixel keeps that plane in memory, and an emissive plane known to be zero is never read.  The values are substituted: the
+    // arithmetic below is the same and so is the result.  (hints.region == NULL and emissive_zero == 0: nothing is known.)
+    // The state byte and the sRGB table's entry are requested together, in front of everything else: one round trip, not two.
+    uint32_t st = 0u;
+    if (valid && hints.region != nullptr) st = hints.region[((size_t)(py >> 5) * hints.tiles32_x + (size_t)(px0 >> 5)) * 4 + (size_t)((py & 31) >> 3)];
+    const float lut_r = lut_g[threadIdx.x];
+    // issue every load first: up to 7 x 16 B per lane in flight
     // NT: streaming (non-temporal) G-buffer reads - together with the streaming stores (store_quad) the frame's 1.2 GB then
     // pass the caches by and the tile pass's texel tables (180 MB) are still in the Infinity Cache when the next frame's
     // tile pass starts.  Either one alone does not help: 929 MB of reads or 265 MB of dirty lines each flush the cache.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define LD16(ptr) ({ u32x4 v_; if (NT) v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr)); else v_ = *reinterpret_cast<const u32x4*>(ptr); \
                      make_uint4(v_.x, v_.y, v_.z, v_.w); })
-    const uint4 dzu = LD16(g_depth + p);
+    const bool known_clear = st == kRegionClear, known_spec = st == kRegionSpec;
+    uint4 dzu = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u), df = make_uint4(0u, 0u, 0u, 0u), n0 = df, n1 = df, e0 = df, e1 = df;
+    uint4 sp = known_spec ? make_uint4(hints.spec_const, hints.spec_const, hints.spec_const, hints.spec_const) : df;
+    if (valid && !known_clear) {
+        dzu = LD16(g_depth + p);
+        df = LD16(g_diff + p);
+        if (!known_spec) sp = LD16(g_spec + p);
+        n0 = LD16(g_nrm + p);
+        n1 = LD16(g_nrm + p + 2);
+        if (!hints.emissive_zero) { e0 = LD16(g_emi + p); e1 = LD16(g_emi + p + 2); }
+    }
+    lut[threadIdx.x] = lut_r;
+    __syncthreads();
+    if (!valid) return;
+    // A wave whose texels all hold the clear values (sky: a fifth of the flythrough's pixels, whole rows of waves) has nothing to
+    // shade: with albedo, F0, occlusion, the normal and the emissive term all zero every product of the model below is a
+    // (finite) factor times zero - the radiance is +0 in every channel, which is what the loop would store.  (Wave-uniform.)
+    {
+        const uint32_t any = (dzu.x ^ 0x3f800000u) | (dzu.y ^ 0x3f800000u) | (dzu.z ^ 0x3f800000u) | (dzu.w ^ 0x3f800000u)
+                           | df.x | df.y | df.z | df.w | sp.x | sp.y | sp.z | sp.w | n0.x | n0.y | n0.z | n0.w | n1.x | n1.y | n1.z | n1.w
+                           | e0.x | e0.y | e0.z | e0.w | e1.x | e1.y | e1.z | e1.w;
+        if (__all(any == 0u)) {
+            const uint32_t z[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            store_quad<PACKED, NT>(out, out_index, z);
+            return;
+        }
+    }
     const float4 dz = make_float4(__uint_as_float(dzu.x), __uint_as_float(dzu.y), __uint_as_float(dzu.z), __uint_as_float(dzu.w));
-    const uint4 df = LD16(g_diff + p);
-    const uint4 sp = LD16(g_spec + p);
-    const uint4 n0 = LD16(g_nrm + p);
-    const uint4 n1 = LD16(g_nrm + p + 2);
-    const uint4 e0 = LD16(g_emi + p);
-    const uint4 e1 = LD16(g_emi + p + 2);
 #undef LD16
 
     const float depth[4] = { dz.x, dz.y, dz.z, dz.w };
@@ -199,6 +225,8 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
     { int rc = vr_deferred_make_args(view, gb->w, gb->h, lights, num_lights, amb_top, amb_bottom, &a, &extra); if (rc) return rc; }
     const size_t npx = (size_t)gb->w * gb->h;
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
+    PlaneHints hints;
+    { int rc = vr_gbuffer_plane_hints(gb, ctx->stream, &hints); if (rc) return rc; }
     VrKernelScope ks(ctx, VR_K_DEFERRED, ctx->stream, true);
     if (packed) {
         const PartTables* pt = nullptr;
@@ -211,7 +239,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         if (pt->num_owned > 0) {
             auto kern = shadow ? k_deferred<true, true, true> : (extra ? k_deferred<true, true> : k_deferred<true, false>);
             VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)pt->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, pt->d_owned_tiles, sh);
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, pt->d_owned_tiles, sh, hints);
         }
     } else {
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
@@ -223,7 +251,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
                                : extra ? (nt ? k_deferred<false, true, false, true> : k_deferred<false, true, false, false>)
                                        : (nt ? k_deferred<false, false, false, true> : k_deferred<false, false, false, false>);
             VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
-                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh);
+                               gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh, hints);
         } else {
             VR_LAUNCH_TIMED(ks, k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, sh, shadow ? 1 : 0);

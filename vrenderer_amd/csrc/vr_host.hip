@@ -489,6 +489,27 @@ int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out)
     return VR_OK;
 }
 
+uint32_t vr_specular_constant(const vr_context* c)
+{
+    // sRGB-encode 1.0 * 0.01 with the context's threshold table (the tile pass's own encode)
+    int lo = 0, hi = 255;
+    const float x = 1.0f * 0.01f;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
+    const uint32_t sc = (uint32_t)lo;
+    return sc | (sc << 8) | (sc << 16) | 0xff000000u;
+}
+
+int vr_gbuffer_plane_hints(vr_gbuffer* g, hipStream_t s, PlaneHints* out)
+{
+    out->region = nullptr; out->spec_const = vr_specular_constant(g->ctx); out->emissive_zero = 0; out->tiles32_x = (g->w + 31) / 32;
+    if (!g->ctx->plane_tracking || g->escaped) return VR_OK;
+    uint8_t* r = nullptr;
+    const int rc = vr_gbuffer_region_prepare(g, s, &r);
+    if (rc) return rc;
+    out->region = r; out->emissive_zero = g->emissive_zero ? 1 : 0;
+    return VR_OK;
+}
+
 extern "C" VR_API int vr_gbuffer_region_census(vr_gbuffer* g, uint32_t counts[4])
 {
     VR_REQUIRE(g && counts, "NULL argument");

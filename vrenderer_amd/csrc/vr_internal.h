@@ -237,6 +237,15 @@ struct vr_gbuffer {
 };
 constexpr uint32_t kRegionSpec = 1u, kRegionClear = 2u;
 int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out);     // allocated and current (vr_host.hip)
+// What a pass that READS the G-buffer may take from the tracking instead of from memory (the lighting passes).
+struct PlaneHints {
+    const uint8_t* region;       // region states (NULL: nothing known per region)
+    uint32_t spec_const;         // the value kRegionSpec stands for
+    int emissive_zero;           // the emissive plane holds only zeros
+    int tiles32_x;               // regions are indexed [32-pixel tile][wave of the tile = 8 rows]
+};
+int vr_gbuffer_plane_hints(vr_gbuffer* g, hipStream_t s, PlaneHints* out);
+uint32_t vr_specular_constant(const vr_context* c);     // main_ps's specular output as the G-buffer holds it (terrain_ps.hlsl:76 -> SRGBA8)
 // (anything else that writes the G-buffer: its depth ranges are stale)
 inline void vr_gbuffer_touch(vr_gbuffer* g) { if (g->ranges_state == vr_gbuffer::RANGES_VALID) g->ranges_state = vr_gbuffer::RANGES_DIRTY; }
 int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s);      // allocated and every entry "none" (vr_host.hip)

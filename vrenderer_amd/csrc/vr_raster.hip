@@ -1733,14 +1733,6 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
 // ---------------------------------------------------------------------------------------
 // host: TerrainPass::Render (TerrainPass.cpp:143-232)
 // ---------------------------------------------------------------------------------------
-static uint32_t host_srgb_encode(const vr_context* c, float x)
-{
-    if (!(x >= 0.0f)) return 0;
-    int lo = 0, hi = 255;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (x >= c->h_srgb_thr[mid]) lo = mid; else hi = mid - 1; }
-    return (uint32_t)lo;
-}
-
 static int make_raster_args(vr_terrain* t, const vr_view* view, const vr_render_params* rp, int w, int h, const vr_partition* part,
                             RasterArgs& a)
 {
@@ -1998,8 +1990,7 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
     // the tile pass consumes verts + bins (a wait queued at prepare time counts only if it sits on the stream this pass runs on)
     if (!(use_prepared && g.main_waited && g.main_wait_stream == s)) VR_HIP(hipStreamWaitEvent(s, g.ev_geo_done, 0));
     g.main_waited = false;
-    const uint32_t sc = host_srgb_encode(ctx, 1.0f * 0.01f);             // terrain_ps.hlsl:76 -> SRGBA8
-    const uint32_t spec_const = sc | (sc << 8) | (sc << 16) | 0xff000000u;
+    const uint32_t spec_const = vr_specular_constant(ctx);               // terrain_ps.hlsl:76 -> SRGBA8
     const int grid = pt ? pt->num_raster_tiles : a.rtx * a.rty;
     // vr_terrain_prepare's start hint: "the context's stream has reached this tile pass".  With dispatch-stamped events that
     // is the stop event of whatever ran last on the stream (the previous frame's lighting pass); else an explicit record.
