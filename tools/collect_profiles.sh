@@ -9,7 +9,7 @@ WHAT=${@:-stats pmc sq}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="--no-cpu-baseline --no-4k"
+B="--no-cpu-baseline --no-4k --no-sustained"     # one timed region: the per-kernel averages are those of the default (tracked) frames only
 run_stats() {  # name, bench args
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$1 --output-format csv -- python3 bench.py $B --steps 30 --warmup 3 ${@:2} > $OUT/stats_$1.log 2>&1
   cp $(ls $OUT/stats_$1/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_$1.csv
