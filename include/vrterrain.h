@@ -278,7 +278,11 @@ VR_API int  vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_gbuffer* g
 VR_API int  vr_terrain_num_chunks(vr_terrain* t, uint32_t* count);
 
 /* ---- render targets ---------------------------------------------------------- */
-/* RenderTargets::Init / Clear (Renderer.h:60-101, Renderer.cpp:382). */
+/* RenderTargets::Init / Clear (Renderer.h:60-101, Renderer.cpp:382).
+ * Under VR_OPT_PLANE_TRACKING (default) the clear is lazy: the next vr_terrain_render that shades the whole frame runs as
+ * "over a cleared target" (what vr_render_params::assume_cleared asks for explicitly) and writes each pixel once; anything else
+ * that looks at the planes first - a lighting pass, a rank's share, a depth-only pass, vr_gbuffer_download / _upload /
+ * _describe - has the clear values written then.  What the planes read as never differs from an eager clear. */
 VR_API int  vr_gbuffer_create(vr_context* ctx, int32_t width, int32_t height, vr_gbuffer** out);
 VR_API void vr_gbuffer_destroy(vr_gbuffer* gb);
 VR_API int  vr_gbuffer_clear(vr_gbuffer* gb);

@@ -1243,6 +1243,76 @@ def test_region_tracking_never_changes_the_gbuffer(scene256, oracle, gpu_ctx):
     assert saw_clear and saw_spec
 
 
+def test_clear_is_lazy_under_the_tracking_and_never_visible(scene256, oracle, gpu_ctx):
+    """RenderTargets::Clear (Renderer.cpp:382) under VR_OPT_PLANE_TRACKING writes nothing by itself: the next whole-frame shaded tile
+    pass runs as 'over a cleared target', anything else that looks at the planes first (download, a lighting pass, a rank's share,
+    a depth-only pass, upload) gets the clear values written then.  Whatever the order, the planes read as Clear + what followed."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    w, h = 416, 236
+    va, vb = (vr.make_view(*scaled_camera(CAMERAS[i], 256), w, h) for i in (0, 5))
+    rp_k = vr.default_render_params(400.0)
+    names = ("depth", "diffuse", "specular", "normals", "emissive")
+    want_a, want_b, cleared = oracle.GBufferHost(w, h), oracle.GBufferHost(w, h), oracle.GBufferHost(w, h)
+    ot.render(va, want_a, rp_k); ot.render(vb, want_b, rp_k)
+
+    def planes(rt):
+        return {k: rt.download(k) for k in names}
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    hdr, hdr2 = vr.HdrImage(gpu_ctx, w, h), vr.HdrImage(gpu_ctx, w, h)
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    sun = [vr.reference_sun()]
+    try:
+        # Clear + Render, the reference's own sequence, frame after frame: no clear kernel runs
+        tp.Render(va, va, rt, rp_k)
+        gpu_ctx.synchronize()
+        gpu_ctx.timing_enable(1)
+        for v, want in ((vb, want_b), (va, want_a), (vb, want_b)):
+            rt.Clear(); tp.Render(v, v, rt, rp_k)
+        gpu_ctx.synchronize()
+        kernels = gpu_ctx.timing_collect()
+        gpu_ctx.timing_enable(False)
+        assert "k_raster" in kernels and not any("clear" in k for k in kernels), sorted(kernels)
+        _assert_gbuffer_equal(want_b, planes(rt), "Clear + Render x 3")
+        # a reader first: the clear happens for it
+        rt.Clear()
+        _assert_gbuffer_equal(cleared, planes(rt), "Clear, then download")
+        tp.Render(va, va, rt, rp_k); rt.Clear()
+        dl.Render(va, rt, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)                    # lights a cleared G-buffer
+        rt2 = vr.RenderTargets(gpu_ctx).Init(w, h)
+        dl.Render(va, rt2, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr2)
+        assert np.array_equal(hdr.download(), hdr2.download())
+        rt2.close()
+        # a rank's share / a depth-only pass over a pending clear
+        tp.Render(vb, vb, rt, rp_k); rt.Clear()
+        tp.Render(va, va, rt, rp_k, vr.Partition(0, 2))
+        got = planes(rt)
+        ty, tx = np.indices((h, w))
+        owned = ((tx // 128 + ty // 128) % 2) == 0
+        for k in names:
+            assert np.array_equal(got[k][owned], getattr(want_a, k)[owned]) and np.array_equal(got[k][~owned], getattr(cleared, k)[~owned]), k
+        tp.Render(vb, vb, rt, rp_k); rt.Clear()
+        tp.Render(va, va, rt, vr.default_render_params(400.0, depth_only=1))
+        got = planes(rt)
+        assert np.array_equal(got["depth"].view(np.uint32), want_a.depth.view(np.uint32))
+        for k in names[1:]:
+            assert np.array_equal(got[k], getattr(cleared, k)), k
+        # upload over a pending clear: the other planes are clear, the uploaded one holds the upload
+        tp.Render(vb, vb, rt, rp_k); rt.Clear()
+        junk = np.full((h, w), 0x01020304, np.uint32)
+        rt.upload("diffuse", junk)
+        got = planes(rt)
+        assert np.array_equal(got["diffuse"], junk) and np.array_equal(got["depth"], cleared.depth) and np.array_equal(got["normals"], cleared.normals)
+        # two clears, then a composite of two views by the depth test
+        rt.Clear(); rt.Clear()
+        both = oracle.GBufferHost(w, h)
+        ot.render(va, both, rp_k); ot.render(vb, both, rp_k)
+        tp.Render(va, va, rt, rp_k); tp.Render(vb, vb, rt, rp_k)
+        _assert_gbuffer_equal(both, planes(rt), "Clear, Render a, Render b")
+    finally:
+        gpu_ctx.timing_enable(False)
+        hdr.close(); hdr2.close(); rt.close()
+
+
 def test_emissive_plane_tracking_never_changes_the_gbuffer(scene256, oracle, gpu_ctx):
     """VR_OPT_PLANE_TRACKING: main_ps writes 0 to the emissive target (terrain_ps.hlsl:80) and Clear writes 0, so the tile pass
     skips the plane while the library knows it is all zero.  Whatever the history - fresh target, foreign writes (upload),

@@ -212,6 +212,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
                    && shadow->light_view->viewport_h == shadow->light_view->viewport_w, "shadow map must be square and match the light view's viewport");
         VR_REQUIRE(shadow->shadow_map->ctx->device == ctx->device, "shadow map lives on another device");
         for (int i = 0; i < 16; i++) sh.w2c[i] = shadow->light_view->world_to_clip[i];
+        { VR_HIP(hipSetDevice(ctx->device)); const int rc = vr_gbuffer_materialise(shadow->shadow_map, ctx->stream); if (rc) return rc; }
         sh.depth = shadow->shadow_map->depth; sh.res = shadow->shadow_map->w; sh.light_index = shadow->light_index;
         sh.bias = shadow->depth_bias; sh.out_of_bounds = lights[shadow->light_index].out_of_bounds_shadow;
     }
@@ -656,6 +657,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         ctx->light_capacity = cap;
     }
     if (!ctx->d_flags) { VR_HIP(hipMalloc(&ctx->d_flags, 64)); VR_HIP(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream)); }
+    { const int rc = vr_gbuffer_materialise(gb, ctx->stream); if (rc) return rc; }       // (a reader: a pending clear happens now)
     ctx->h_lights.resize((size_t)num_lights);
     for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i], false); if (rc) return rc; }
     // a scene's light list rarely changes between frames: upload only when it differs from what the device holds

@@ -454,15 +454,12 @@ static int fill_u32(hipStream_t s, void* ptr, size_t count, uint32_t v)
     return VR_OK;
 }
 
-extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
+static int gbuffer_clear_now(vr_gbuffer* g, hipStream_t s)
 {
-    VR_REQUIRE(g != nullptr, "gbuffer is NULL");
-    VR_HIP(hipSetDevice(g->ctx->device));
     vr_gbuffer_touch(g);
     size_t n = (size_t)g->w * g->h;
-    hipStream_t s = g->ctx->stream;
     int rc;
-    VrKernelScope scope(g->ctx, VR_K_CLEAR);
+    VrKernelScope scope(g->ctx, VR_K_CLEAR, s);
     if ((rc = fill_u32(s, g->depth, n, 0x3f800000u))) return rc;      // depth = 1.0 (non-reversed)
     if ((rc = fill_u32(s, g->diffuse, n, 0u))) return rc;
     if ((rc = fill_u32(s, g->specular, n, 0u))) return rc;
@@ -470,7 +467,28 @@ extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
     if ((rc = fill_u32(s, g->emissive, n * 2, 0u))) return rc;
     g->emissive_zero = true;               // (stream-ordered: every later pass on the context's stream sees the zeros)
     g->region_fill = (int)kRegionClear;    // every region holds the clear values (the array is filled when a tile pass next asks for it)
+    g->clear_pending = false;
     return VR_OK;
+}
+
+extern "C" VR_API int vr_gbuffer_clear(vr_gbuffer* g)
+{
+    VR_REQUIRE(g != nullptr, "gbuffer is NULL");
+    VR_HIP(hipSetDevice(g->ctx->device));
+    if (g->ctx->plane_tracking && !g->escaped && g->cleared_once) {
+        // lazy (vr_internal.h): the planes are cleared by the next whole-frame tile pass, or by whoever looks at them first
+        vr_gbuffer_touch(g);
+        g->clear_pending = true;
+        return VR_OK;
+    }
+    g->cleared_once = true;
+    return gbuffer_clear_now(g, g->ctx->stream);
+}
+
+int vr_gbuffer_materialise(vr_gbuffer* g, hipStream_t s)
+{
+    if (!g->clear_pending) return VR_OK;
+    return gbuffer_clear_now(g, s);
 }
 
 int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out)
@@ -502,6 +520,7 @@ uint32_t vr_specular_constant(const vr_context* c)
 int vr_gbuffer_plane_hints(vr_gbuffer* g, hipStream_t s, PlaneHints* out)
 {
     out->region = nullptr; out->spec_const = vr_specular_constant(g->ctx); out->emissive_zero = 0; out->tiles32_x = (g->w + 31) / 32;
+    { const int rc = vr_gbuffer_materialise(g, s); if (rc) return rc; }       // (a reader: a pending clear happens now)
     if (!g->ctx->plane_tracking || g->escaped) return VR_OK;
     uint8_t* r = nullptr;
     const int rc = vr_gbuffer_region_prepare(g, s, &r);
@@ -517,6 +536,7 @@ extern "C" VR_API int vr_gbuffer_region_census(vr_gbuffer* g, uint32_t counts[4]
     const int tiles = ((g->w + 31) / 32) * ((g->h + 31) / 32);
     counts[3] = (uint32_t)tiles * 4u;
     if (!g->ctx->plane_tracking || g->escaped) { counts[0] = counts[3]; return VR_OK; }      // no region is known to hold anything
+    if (g->clear_pending) { counts[2] = counts[3]; return VR_OK; }            // (cleared, as far as anyone can tell)
     if (!g->d_region || g->region_fill >= 0) { counts[g->region_fill == (int)kRegionClear ? 2 : 0] = counts[3]; return VR_OK; }
     VR_HIP(hipSetDevice(g->ctx->device));
     std::vector<uint8_t> h((size_t)tiles * 4);
@@ -529,7 +549,7 @@ extern "C" VR_API int vr_gbuffer_region_census(vr_gbuffer* g, uint32_t counts[4]
 extern "C" VR_API int vr_gbuffer_plane_known_zero(vr_gbuffer* g, int plane)
 {
     if (!g || plane != 4) return 0;
-    return (g->ctx->plane_tracking && g->emissive_zero && !g->escaped) ? 1 : 0;
+    return (g->ctx->plane_tracking && (g->emissive_zero || g->clear_pending) && !g->escaped) ? 1 : 0;
 }
 
 __global__ void k_fill_u32x2(uint2* p, size_t n, uint32_t x, uint32_t y)
@@ -556,6 +576,7 @@ int vr_gbuffer_ranges_prepare(vr_gbuffer* g, hipStream_t s)
 extern "C" VR_API int vr_gbuffer_describe(vr_gbuffer* g, vr_gbuffer_desc* d)
 {
     VR_REQUIRE(g && d, "NULL argument");
+    { VR_HIP(hipSetDevice(g->ctx->device)); const int rc = vr_gbuffer_materialise(g, g->ctx->stream); if (rc) return rc; }
     vr_gbuffer_touch(g);           // the caller gets the device pointers: whatever it writes through them is unknown here,
     g->escaped = true;             // now and for as long as the G-buffer lives (no depth ranges, no plane-state tracking any more)
     g->emissive_zero = false;
@@ -584,6 +605,7 @@ extern "C" VR_API int vr_gbuffer_download(vr_gbuffer* g, int plane, void* host, 
     void* p; size_t nb; int rc = plane_info(g, plane, &p, &nb); if (rc) return rc;
     VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
     VR_HIP(hipSetDevice(g->ctx->device));
+    if ((rc = vr_gbuffer_materialise(g, g->ctx->stream))) return rc;
     VR_HIP(hipMemcpyAsync(host, p, nb, hipMemcpyDeviceToHost, g->ctx->stream));
     VR_HIP(hipStreamSynchronize(g->ctx->stream));
     return VR_OK;
@@ -594,6 +616,7 @@ extern "C" VR_API int vr_gbuffer_upload(vr_gbuffer* g, int plane, const void* ho
     void* p; size_t nb; int rc = plane_info(g, plane, &p, &nb); if (rc) return rc;
     VR_REQUIRE(bytes == nb, "byte count does not match the plane size");
     VR_HIP(hipSetDevice(g->ctx->device));
+    if ((rc = vr_gbuffer_materialise(g, g->ctx->stream))) return rc;
     vr_gbuffer_touch(g);
     if (plane == 4) g->emissive_zero = false;
     g->region_fill = 0;                    // (no region is known clear - that includes the emissive plane - or constant any more)

@@ -234,7 +234,14 @@ struct vr_gbuffer {
     uint8_t* d_region = nullptr;
     int region_tiles = 0;
     int region_fill = 0;
+    // RenderTargets::Clear (vr_gbuffer_clear) under the tracking is LAZY: the next tile pass that writes every pixel of every plane
+    // anyway (whole frame, shaded) runs as "over a cleared target" and the 929 MB of clear values are never written twice;
+    // anything else that looks at the planes first (a lighting pass, a partitioned / depth-only / fused pass, download, upload,
+    // describe) materialises the clear (vr_gbuffer_materialise).  Clear + Render then costs what Render(assume_cleared) costs.
+    bool clear_pending = false;
+    bool cleared_once = false;       // (the clear at creation is a real one: the allocation holds anything)
 };
+int vr_gbuffer_materialise(vr_gbuffer* g, hipStream_t s);      // a pending clear is written now, on `s` (vr_host.hip)
 constexpr uint32_t kRegionSpec = 1u, kRegionClear = 2u;
 int vr_gbuffer_region_prepare(vr_gbuffer* g, hipStream_t s, uint8_t** out);     // allocated and current (vr_host.hip)
 // What a pass that READS the G-buffer may take from the tracking instead of from memory (the lighting passes).

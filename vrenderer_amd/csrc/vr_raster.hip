@@ -1971,6 +1971,13 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
     if (a.world > 1 && (rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt))) return rc;
+    // RenderTargets::Clear is lazy under the plane-state tracking (vr_gbuffer::clear_pending): a shaded pass over the whole frame
+    // writes every pixel of every plane anyway and runs as "over a cleared target" - Clear + Render is one pass over the
+    // memory; any other pass (a rank's share, depth only, the fused variant) needs the clear values in memory first
+    if (gb->clear_pending) {
+        if (a.world <= 1 && !a.depth_only && lit_req == nullptr) { a.assume_cleared = 1; gb->clear_pending = false; }
+        else if ((rc = vr_gbuffer_materialise(gb, s))) return rc;
+    }
 
     // a set prepared for exactly this frame, else a free one (the oldest prepared set is given up if all are taken)
     int gi = -1;
