@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
                                                          const uint32_t* __restrict__ g_spec, const uint2* __restrict__ g_nrm,
                                                          const uint2* __restrict__ g_emi, uint2* __restrict__ out,
                                                          const float* __restrict__ lut_g, const int32_t* __restrict__ owned_tiles,
-                                                         const uint32_t* __restrict__ lists, int stride, int tiles32_x)
+                                                         const uint32_t* __restrict__ lists, int stride, int tiles32_x, PlaneHints hints)
 {
 #pragma clang fp contract(fast)
     __shared__ float lut[256];
@@ -560,9 +560,23 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
     const uint32_t* __restrict__ list = lists + (size_t)(gy * tiles32_x + gx) * stride;
     const uint32_t n = listed ? list[0] : 0u;
 
+    // Plane-state tracking (as in k_deferred): this light tile is a raster tile's four regions - one word.  A tile that holds only
+    // clear values has no light and no surface: +0 everywhere, nothing read (workgroup-uniform, in front of the barrier); a region's
+    // constant specular plane and a zero emissive plane are not read.
+    uint32_t st = 0u;
+    if (hints.region != nullptr && listed) {
+        const uint32_t st4 = reinterpret_cast<const uint32_t*>(hints.region)[gy * tiles32_x + gx];
+        if (st4 == kRegionClear * 0x01010101u) {
+            const uint32_t z[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            if (inside) store_quad<PACKED, NT>(out, out_index, z);
+            return;
+        }
+        st = (st4 >> (8 * (ly >> 3))) & 255u;
+    }
     float depth[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
     uint32_t dfa[4] = { 0, 0, 0, 0 }, spa[4] = { 0, 0, 0, 0 }, na[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ea[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (inside) {
+    if (st == kRegionSpec) spa[0] = spa[1] = spa[2] = spa[3] = hints.spec_const;
+    if (inside && st != kRegionClear) {
         const size_t p = (size_t)py * a.w + px0;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // NT: streaming loads, as in k_deferred
 #define LD16(ptr) ({ u32x4 v_; if (NT) v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr)); else v_ = *reinterpret_cast<const u32x4*>(ptr); \
@@ -570,11 +584,12 @@ __global__ __launch_bounds__(256) void k_deferred_tiled(DeferredArgs a, const De
         const uint4 dzu = LD16(g_depth + p);
         const float4 dz = make_float4(__uint_as_float(dzu.x), __uint_as_float(dzu.y), __uint_as_float(dzu.z), __uint_as_float(dzu.w));
         const uint4 df = LD16(g_diff + p);
-        const uint4 sp = LD16(g_spec + p);
+        uint4 sp = make_uint4(spa[0], spa[1], spa[2], spa[3]);
+        if (st != kRegionSpec) sp = LD16(g_spec + p);
         const uint4 n0 = LD16(g_nrm + p);
         const uint4 n1 = LD16(g_nrm + p + 2);
-        const uint4 e0 = LD16(g_emi + p);
-        const uint4 e1 = LD16(g_emi + p + 2);
+        uint4 e0 = make_uint4(0u, 0u, 0u, 0u), e1 = e0;
+        if (!hints.emissive_zero) { e0 = LD16(g_emi + p); e1 = LD16(g_emi + p + 2); }
 #undef LD16
         depth[0] = dz.x; depth[1] = dz.y; depth[2] = dz.z; depth[3] = dz.w;
         dfa[0] = df.x; dfa[1] = df.y; dfa[2] = df.z; dfa[3] = df.w; spa[0] = sp.x; spa[1] = sp.y; spa[2] = sp.z; spa[3] = sp.w;
@@ -657,7 +672,8 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         ctx->light_capacity = cap;
     }
     if (!ctx->d_flags) { VR_HIP(hipMalloc(&ctx->d_flags, 64)); VR_HIP(hipMemsetAsync(ctx->d_flags, 0, 64, ctx->stream)); }
-    { const int rc = vr_gbuffer_materialise(gb, ctx->stream); if (rc) return rc; }       // (a reader: a pending clear happens now)
+    PlaneHints hints;                                         // (a reader: a pending clear happens now)
+    { const int rc = vr_gbuffer_plane_hints(gb, ctx->stream, &hints); if (rc) return rc; }
     ctx->h_lights.resize((size_t)num_lights);
     for (int i = 0; i < num_lights; i++) { int rc = fill_light(lights[i], ctx->h_lights[i], false); if (rc) return rc; }
     // a scene's light list rarely changes between frames: upload only when it differs from what the device holds
@@ -717,7 +733,7 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
             VrKernelScope ks(ctx, VR_K_DEFERRED_TILED, ctx->stream, true);
             VR_LAUNCH_TIMED(ks, (k_deferred_tiled<true, VR_TILED_PXB>), dim3((unsigned)pt->num_owned * kSubTiles), dim3(256), ctx->stream, a,
                             ctx->d_lights, gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data,
-                            ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx);
+                            ctx->d_srgb_lut, pt->d_owned_tiles, ctx->d_light_lists, stride, tx, hints);
         }
     } else {
         VR_REQUIRE((size_t)gb->w * gb->h * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
@@ -729,10 +745,10 @@ extern "C" VR_API int vr_deferred_light_tiled(vr_context* ctx, const vr_view* vi
         const bool nt = true;                                         // as in the streaming pass
         if (nt) VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, true>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,
                                 gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
-                                (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
+                                (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, hints);
         else VR_LAUNCH_TIMED(ks, (k_deferred_tiled<false, VR_TILED_PXB, false>), dim3((unsigned)(tx * ty)), dim3(256), ctx->stream, a, ctx->d_lights,
                              gb->depth, gb->diffuse, gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut,
-                             (const int32_t*)nullptr, ctx->d_light_lists, stride, tx);
+                             (const int32_t*)nullptr, ctx->d_light_lists, stride, tx, hints);
     }
     VR_HIP(hipGetLastError());
     return VR_OK;
