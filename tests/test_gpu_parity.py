@@ -956,7 +956,7 @@ def test_full_size_8k_properties(scene2048, gpu_ctx):
 def test_full_size_8k_frame_against_the_oracle(scene2048, oracle, gpu_ctx):
     """One whole frame at BASELINE's full size (7680x4320, flythrough frame 30) against the CPU oracle: all 33.2 M
     pixels of every G-buffer plane bit-exact, HDR per-channel RMS <= 1e-4 (the oracle needs ~20 s for it)."""
-    from bench import flythrough_camera
+    from vrenderer_amd.scene import flythrough_camera
     W, H = 7680, 4320
     eye, tgt = flythrough_camera(30)
     v = vr.make_view(eye, tgt, W, H)
