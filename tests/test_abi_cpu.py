@@ -220,6 +220,25 @@ def test_header_is_valid_c(tmp_path):
     assert subprocess.run([str(tmp_path / "c_check")]).returncode == 0
 
 
+def test_ctypes_mirrors_have_the_header_s_struct_sizes(tmp_path):
+    """The ctypes structures of vrenderer_amd/capi.py against sizeof() of the C declarations they mirror."""
+    import subprocess
+    from vrenderer_amd import capi
+    pairs = [("vr_view", capi.View), ("vr_light", capi.Light), ("vr_instance", capi.Instance), ("vr_terrain_params", capi.TerrainParams),
+             ("vr_render_params", capi.RenderParams), ("vr_partition", capi.Partition), ("vr_shadow_params", capi.ShadowParams),
+             ("vr_shadow_binding", capi.ShadowBinding), ("vr_tonemap_params", capi.TonemapParams), ("vr_frame_desc", capi.FrameDesc),
+             ("vr_gbuffer_desc", capi.GBufferDesc)]
+    src = tmp_path / "sizes.c"
+    src.write_text("#include <stdio.h>\n#include <vrterrain.h>\nint main(void) {\n"
+                   + "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n, _ in pairs) + "    return 0;\n}\n")
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "sizes")], check=True,
+                   capture_output=True, text=True)
+    out = dict(l.split() for l in subprocess.run([str(tmp_path / "sizes")], capture_output=True, text=True, check=True).stdout.splitlines())
+    import ctypes as C
+    for n, t in pairs:
+        assert int(out[n]) == C.sizeof(t), (n, out[n], C.sizeof(t))
+
+
 def test_png_ingest_round_trip(tmp_path, oracle):
     """Row f4: PNG heightmap / albedo ingest gives back exactly the bytes TerrainPass.Init takes."""
     from vrenderer_amd import io as vio
