@@ -1666,8 +1666,9 @@ __global__ __launch_bounds__(kRT, (LIT ? 4 : TILE == 32 ? VR_RASTER_WAVES_32 : V
             if constexpr (LIT) {
                 // the pixel as the lighting pass would read it back from the G-buffer: the encoded texel (a cleared one where nothing
                 // was drawn), the same decode, the same shading, the same half conversion
-                float lrgb[3];
-                shade_pixel<false>(lit.da, s_lut, gx, gy0 + k, __uint_as_float(dep), dif, cov ? spec_const : 0u, nn0, nn1, 0u, 0u, lrgb);
+                // (a wave of uncovered pixels - cleared texels - shades to +0 in every channel: vr_deferred.hip, k_deferred; wave-uniform)
+                float lrgb[3] = { 0.0f, 0.0f, 0.0f };
+                if (__any(cov)) shade_pixel<false>(lit.da, s_lut, gx, gy0 + k, __uint_as_float(dep), dif, cov ? spec_const : 0u, nn0, nn1, 0u, 0u, lrgb);
                 const uint32_t o0 = vr_float_to_half(lrgb[0]) | (vr_float_to_half(lrgb[1]) << 16), o1 = vr_float_to_half(lrgb[2]);
                 __builtin_amdgcn_raw_buffer_store_b32(dep, rgb, pix4, 0, aux);
                 if (lit.tile_slot == nullptr) {
