@@ -905,6 +905,45 @@ def test_too_many_instances_and_empty_selection(scene256, oracle, gpu_ctx):
     rt.close()
 
 
+def test_full_size_8k_flythrough_is_the_same_with_and_without_plane_tracking(scene2048, gpu_ctx):
+    """The bench's own frames (7680x4320, flythrough views 0, 1, 2, 40, 41 - sky above the horizon, terrain below) rendered and lit
+    with VR_OPT_PLANE_TRACKING on (regions skipped, planes not re-read, lazy clear) and off: every G-buffer plane and HdrColor
+    byte for byte, frame after frame on the same targets; and a fair share of the regions really was skipped."""
+    from vrenderer_amd.scene import flythrough_camera
+    tp = scene2048["tp"]
+    W, H = 7680, 4320
+    lights = [vr.reference_sun()]
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    rp = vr.default_render_params(400.0, assume_cleared=1)
+    frames = (0, 1, 2, 40, 41)
+    digests = {}
+    for tracking in (False, True):
+        gpu_ctx.set_plane_tracking(tracking)
+        rt = vr.RenderTargets(gpu_ctx).Init(W, H)
+        hdr = vr.HdrImage(gpu_ctx, W, H)
+        try:
+            for i in frames:
+                v = vr.make_view(*flythrough_camera(i), W, H)
+                if i == 40:
+                    rt.Clear()                                   # (lazy under the tracking) + a keep-what-is-there pass
+                    tp.Render(v, v, rt, vr.default_render_params(400.0))
+                else:
+                    tp.Render(v, v, rt, rp)
+                dl.Render(v, rt, lights, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+                got = [rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")] + [hdr.download()]
+                if tracking:
+                    for name, a, b in zip(("depth", "diffuse", "specular", "normals", "emissive", "HdrColor"), digests[i], got):
+                        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"frame {i}: {name} differs with the tracking on"
+                else:
+                    digests[i] = got
+            if tracking:
+                c = rt.region_census()
+                assert c["clear"] > 0.1 * c["total"] and c["specular_constant"] > 0.5 * c["total"], c
+        finally:
+            gpu_ctx.set_plane_tracking(True)
+            hdr.close(); rt.close()
+
+
 def test_full_size_8k_properties(scene2048, gpu_ctx):
     """BASELINE's full size (7680x4320, heightmap 2048^2) through size-independent properties: the
     frame is deterministic, Clear+Render equals the fused-clear render, the default camera leaves no
