@@ -2105,6 +2105,72 @@ def test_random_texture_fuzz_bit_exact(oracle, gpu_ctx):
             tp.close(); ot.close()
 
 
+def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx):
+    """A random sequence of everything that touches a G-buffer - passes over a 'cleared' target, keep-what-is-there passes, Clear
+    (lazy), uploads of junk into single planes, wireframe / depth-only / partitioned passes, lighting passes - with the planes
+    compared only now and then, so that region states, the zero-emissive flag and a pending clear live through several
+    operations.  The planes must equal an oracle-side mirror of the same sequence, and a lighting pass over the tracked target
+    must equal, bit for bit, the same pass over a second target that holds the mirror's planes and knows nothing about them."""
+    ot, tp = scene256["ot"], scene256["tp"]
+    rng = np.random.default_rng(20261005)
+    w, h = 352, 200
+    cams = [scaled_camera(c, 256) for c in CAMERAS[:6]] + [((10.0, 60.0, 10.0), (60.0, 200.0, 60.0))]      # the last one: sky only
+    views = [vr.make_view(e, t, w, h) for e, t in cams]
+    names = ("depth", "diffuse", "specular", "normals", "emissive")
+    rp_k = vr.default_render_params(400.0)
+    rt = vr.RenderTargets(gpu_ctx).Init(w, h)
+    rt_ref = vr.RenderTargets(gpu_ctx).Init(w, h)
+    hdr, hdr_ref = vr.HdrImage(gpu_ctx, w, h), vr.HdrImage(gpu_ctx, w, h)
+    dl = vr.DeferredLightingPass(gpu_ctx)
+    sun = [vr.reference_sun()]
+    cur = oracle.GBufferHost(w, h)
+    ty, tx = np.indices((h, w))
+    ops = ["cleared", "cleared", "cleared", "keep", "clear", "upload", "wire", "depth_only", "part", "light", "check"]
+    try:
+        for step in range(160):
+            op = str(rng.choice(ops))
+            v = views[int(rng.integers(len(views)))]
+            if op == "cleared":
+                cur = oracle.GBufferHost(w, h); ot.render(v, cur, rp_k)
+                tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1, depth_ranges=int(rng.integers(2))))
+            elif op == "keep":
+                ot.render(v, cur, rp_k); tp.Render(v, v, rt, rp_k)
+            elif op == "clear":
+                cur = oracle.GBufferHost(w, h); rt.Clear()
+            elif op == "upload":
+                k = names[int(rng.integers(5))]
+                arr = getattr(cur, k)
+                junk = rng.integers(0, 256, arr.shape + (arr.dtype.itemsize,), dtype=np.uint8).view(arr.dtype).reshape(arr.shape)
+                if k == "depth":
+                    junk = rng.random(arr.shape, dtype=np.float32)        # (finite depths)
+                arr[...] = junk; rt.upload(k, junk)
+            elif op == "wire":
+                cur = oracle.GBufferHost(w, h); rpw = vr.default_render_params(400.0, wireframe=1)
+                ot.render(v, cur, rpw); tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1, wireframe=1))
+            elif op == "depth_only":
+                rpd = vr.default_render_params(400.0, depth_only=1)
+                ot.render(v, cur, rpd); tp.Render(v, v, rt, rpd)
+            elif op == "part":
+                world = int(rng.integers(2, 4)); rank = int(rng.integers(world))
+                want = oracle.GBufferHost(w, h); ot.render(v, want, rp_k)
+                owned = ((tx // 128 + ty // 128) % world) == rank
+                for k in names:
+                    getattr(cur, k)[owned] = getattr(want, k)[owned]
+                tp.Render(v, v, rt, vr.default_render_params(400.0, assume_cleared=1), vr.Partition(rank, world))
+            elif op == "light":
+                for k in names:
+                    rt_ref.upload(k, getattr(cur, k))                    # (an upload: nothing is known about rt_ref's planes)
+                dl.Render(v, rt, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+                dl.Render(v, rt_ref, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
+                a, b = hdr.download(), hdr_ref.download()
+                assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"step {step}: lighting differs on {np.argwhere(a.view(np.uint16) != b.view(np.uint16))[:4].tolist()}"
+            if op == "check" or step % 7 == 6:
+                _assert_gbuffer_equal(cur, {k: rt.download(k) for k in names}, f"step {step} ({op})")
+    finally:
+        for o in (hdr, hdr_ref, rt, rt_ref):
+            o.close()
+
+
 def test_api_sequence_fuzz(oracle, gpu_ctx):
     """A random sequence of the frame-loop calls (Render, Prepare for the same or other views - up to two frames ahead -,
     prepared frames consumed later, lock-view renders, a rank's partition with and without a prepared set, SetHeight toggles,
