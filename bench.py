@@ -840,7 +840,11 @@ def main():
                               "needs ~15 ms of load after the host-side set-up to reach its sustained clocks (same 20 frames: 0.585 ms straight "
                               "after 5 warm-up frames, 0.549 ms after a lap; --prewarm-laps 0 for the raw figure)") if args.prewarm_laps else None,
             "sustained": sustained,
-            "without_plane_tracking": untracked,
+            "without_plane_tracking": (dict(untracked, roofline=(lambda us: {"kernel": light_kernel, "bound": "hbm", "avg_us": us,
+                                                   "achieved": round(DEFERRED_BYTES_PER_PX * owned_px / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(DEFERRED_BYTES_PER_PX * owned_px / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "note": "all 36 B/pixel moved: the lighting pass as a pure stream"})(untracked["kernels"][light_kernel]["avg_us"]))
+                                       if untracked and light_kernel in untracked.get("kernels", {}) else untracked),
             "config": {"workload": f"{W}x{H} terrain flythrough (120-frame circle r=600 y=250), heightmap {size}^2, "
                                    + (f"1 sun + {args.lights - 1} point lights (seed 9001, range 20-80) through the tiled pass; " if tiled
                                       else "1 directional light; ")
