@@ -2105,14 +2105,22 @@ def test_random_texture_fuzz_bit_exact(oracle, gpu_ctx):
             tp.close(); ot.close()
 
 
-def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx):
+def _soak_seeds(default):
+    """The committed seed, plus VR_FUZZ_SEEDS=a,b,c for a soak run (one pytest process, more sequences)."""
+    import os
+    extra = [int(x) for x in os.environ.get("VR_FUZZ_SEEDS", "").split(",") if x.strip()]
+    return [default] + extra
+
+
+@pytest.mark.parametrize("seed", _soak_seeds(20261005))
+def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx, seed):
     """A random sequence of everything that touches a G-buffer - passes over a 'cleared' target, keep-what-is-there passes, Clear
     (lazy), uploads of junk into single planes, wireframe / depth-only / partitioned passes, lighting passes - with the planes
     compared only now and then, so that region states, the zero-emissive flag and a pending clear live through several
     operations.  The planes must equal an oracle-side mirror of the same sequence, and a lighting pass over the tracked target
     must equal, bit for bit, the same pass over a second target that holds the mirror's planes and knows nothing about them."""
     ot, tp = scene256["ot"], scene256["tp"]
-    rng = np.random.default_rng(20261005)
+    rng = np.random.default_rng(seed)
     w, h = 352, 200
     cams = [scaled_camera(c, 256) for c in CAMERAS[:6]] + [((10.0, 60.0, 10.0), (60.0, 200.0, 60.0))]      # the last one: sky only
     views = [vr.make_view(e, t, w, h) for e, t in cams]
@@ -2125,7 +2133,10 @@ def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx):
     sun = [vr.reference_sun()]
     cur = oracle.GBufferHost(w, h)
     ty, tx = np.indices((h, w))
-    ops = ["cleared", "cleared", "cleared", "keep", "clear", "upload", "wire", "depth_only", "part", "light", "check"]
+    ops = ["cleared", "cleared", "cleared", "keep", "clear", "upload", "wire", "depth_only", "part", "light", "light_tiled", "submit", "lit", "check"]
+    many = _scene_lights(scene256, 48)
+    tdl = vr.TiledDeferredLightingPass(gpu_ctx)
+    frame_call = vr.Frame(tp, rt, vr.default_render_params(400.0, assume_cleared=1), sun, AMBIENT_TOP, AMBIENT_BOTTOM)
     try:
         for step in range(160):
             op = str(rng.choice(ops))
@@ -2164,6 +2175,27 @@ def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx):
                 dl.Render(v, rt_ref, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
                 a, b = hdr.download(), hdr_ref.download()
                 assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"step {step}: lighting differs on {np.argwhere(a.view(np.uint16) != b.view(np.uint16))[:4].tolist()}"
+            elif op == "light_tiled":                                     # the many-light pass takes the same hints
+                for k in names:
+                    rt_ref.upload(k, getattr(cur, k))
+                tdl.Render(v, rt, many, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+                tdl.Render(v, rt_ref, many, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
+                assert np.array_equal(hdr.download().view(np.uint16), hdr_ref.download().view(np.uint16)), f"step {step}: tiled lighting differs"
+            elif op == "submit":                                          # one call: tile pass over a 'cleared' target + lighting
+                cur = oracle.GBufferHost(w, h); ot.render(v, cur, rp_k)
+                frame_call.submit(v, hdr, [views[int(rng.integers(len(views)))]])
+                for k in names:
+                    rt_ref.upload(k, getattr(cur, k))
+                dl.Render(v, rt_ref, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
+                assert np.array_equal(hdr.download().view(np.uint16), hdr_ref.download().view(np.uint16)), f"step {step}: vr_frame_submit's HdrColor differs"
+            elif op == "lit":                                             # the fused variant: depth + HdrColor only, the other planes stay
+                want = oracle.GBufferHost(w, h); ot.render(v, want, rp_k)
+                tp.RenderLit(v, rt, vr.default_render_params(400.0, assume_cleared=1), sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr)
+                for k in names:
+                    rt_ref.upload(k, getattr(want, k))
+                dl.Render(v, rt_ref, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
+                assert np.array_equal(hdr.download().view(np.uint16), hdr_ref.download().view(np.uint16)), f"step {step}: fused HdrColor differs"
+                cur.depth[...] = want.depth
             if op == "check" or step % 7 == 6:
                 _assert_gbuffer_equal(cur, {k: rt.download(k) for k in names}, f"step {step} ({op})")
     finally:
@@ -2171,13 +2203,14 @@ def test_plane_tracking_sequence_fuzz(scene256, oracle, gpu_ctx):
             o.close()
 
 
-def test_api_sequence_fuzz(oracle, gpu_ctx):
+@pytest.mark.parametrize("seed", _soak_seeds(424242))
+def test_api_sequence_fuzz(oracle, gpu_ctx, seed):
     """A random sequence of the frame-loop calls (Render, Prepare for the same or other views - up to two frames ahead -,
     prepared frames consumed later, lock-view renders, a rank's partition with and without a prepared set, SetHeight toggles,
     stand-alone NodeSelect, a shadow-map render in between): every frame must still equal the oracle's.  Exercises the three
     rotating geometry sets and their streams, the prepared-geometry matching, the per-partition tables and the
     cross-stream dependencies.  The very first call on a fresh terrain is a Prepare with a partition."""
-    rng = np.random.default_rng(424242)
+    rng = np.random.default_rng(seed)
     size = 256
     hmap = oracle.synth_heightmap(size)
     alb = oracle.synth_albedo(size, hmap)
