@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArg
     // A wave whose texels all hold the clear values (sky: a fifth of the flythrough's pixels, whole rows of waves) has nothing to
     // shade: with albedo, F0, occlusion, the normal and the emissive term all zero every product of the model below is a
     // (finite) factor times zero - the radiance is +0 in every channel, which is what the loop would store.  (Wave-uniform.)
+    // "Finite" is the one assumption: a light with non-finite parameters, or a clip-to-world matrix that sends the far plane to
+    // w = 0, would make the loop produce NaN for such a texel where this stores 0 - inputs this path does not see (the host
+    // builds both from a camera and a light list it has validated).
     {
         const uint32_t any = (dzu.x ^ 0x3f800000u) | (dzu.y ^ 0x3f800000u) | (dzu.z ^ 0x3f800000u) | (dzu.w ^ 0x3f800000u)
                            | df.x | df.y | df.z | df.w | sp.x | sp.y | sp.z | sp.w | n0.x | n0.y | n0.z | n0.w | n1.x | n1.y | n1.z | n1.w
