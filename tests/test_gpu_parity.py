@@ -871,6 +871,36 @@ def test_scratch_grows_by_high_water_mark_and_reports_sticky_conditions(scene204
     rt.close()
 
 
+def test_frame_submit_passes_a_sticky_condition_on_and_still_queues_its_frame(scene2048, oracle, gpu_ctx, monkeypatch):
+    """vr_frame_submit with a scratch that is far too small: the first frame is drawn without the excess; the second call returns
+    VR_ERR_OVERFLOW once - behind its own launches: its G-buffer and HdrColor are complete - and the third is clean."""
+    import ctypes as C
+    h, a, ot = scene2048["h"], scene2048["a"], scene2048["ot"]
+    w, hh = 640, 360
+    v = vr.make_view(*CAMERAS[0], w, hh)
+    want = oracle.GBufferHost(w, hh)
+    assert ot.render(v, want, vr.default_render_params(400.0)) > 100
+    monkeypatch.setenv("VR_SCRATCH_INITIAL_NODES", "32")
+    tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+    monkeypatch.delenv("VR_SCRATCH_INITIAL_NODES")
+    rt = vr.RenderTargets(gpu_ctx).Init(w, hh)
+    hdr, hdr_ref = vr.HdrImage(gpu_ctx, w, hh), vr.HdrImage(gpu_ctx, w, hh)
+    sun = [vr.reference_sun()]
+    fr = vr.Frame(tp, rt, vr.default_render_params(400.0, assume_cleared=1), sun, AMBIENT_TOP, AMBIENT_BOTTOM)
+    try:
+        fr.submit(v, hdr)                                        # truncated, not reported yet
+        gpu_ctx.synchronize()
+        d = fr.desc
+        rc = gpu_ctx.lib.vr_frame_submit(tp.handle, rt.handle, C.byref(d))
+        assert rc == vr.capi.VR_ERR_OVERFLOW, rc
+        _assert_gbuffer_equal(want, {k: rt.download(k) for k in ("depth", "diffuse", "specular", "normals", "emissive")}, "the reporting call's own frame")
+        vr.DeferredLightingPass(gpu_ctx).Render(v, rt, sun, AMBIENT_TOP, AMBIENT_BOTTOM, hdr_ref)
+        assert np.array_equal(hdr.download().view(np.uint16), hdr_ref.download().view(np.uint16))
+        assert gpu_ctx.lib.vr_frame_submit(tp.handle, rt.handle, C.byref(d)) == vr.capi.VR_OK
+    finally:
+        hdr.close(); hdr_ref.close(); rt.close(); tp.close()
+
+
 def test_too_many_instances_and_empty_selection(scene256, oracle, gpu_ctx):
     """MAX_INSTANCES overflow is an assert in the reference (TerrainPass.cpp:238): here an error code,
     with the first max_instances nodes still in order.  A camera that sees nothing selects nothing."""
