@@ -246,6 +246,10 @@ def main():
     from vrenderer_amd.scene import AMBIENT_BOTTOM, AMBIENT_TOP, DEFAULT_EYE, DEFAULT_TARGET, params
 
     W, H, size = args.width, args.height, args.size
+    # host housekeeping first, device set-up last: a full collection takes ~40 ms, and a device that sits idle for that long right
+    # before the warm-up frames starts them from its idle clocks (the same 20 frames: 0.49 ms each then, 0.44 at sustained clocks)
+    import gc
+    gc.collect()
     ctx = vr.Context(local_rank)
     if args.raster_tile:
         ctx.set_raster_tile(args.raster_tile)
@@ -517,8 +521,7 @@ def main():
     # after 5 warm-up frames, 0.547-0.550 ms after a lap; profiles/r03_clock_ramp.txt).  Round 3 rendered an untimed lap here
     # by default; now --prewarm-laps defaults to 0 and the figure after a lap of load is measured in a SECOND timed region
     # behind the first and reported beside it ("sustained").
-    import gc
-    gc.collect(); gc.disable()               # no collector pause while the host queues the warm-up and timed frames (20 frames are 11 ms);
+    gc.disable()                             # (collected before the device set-up, above) no collector pause while the host queues the warm-up and timed frames (20 frames are 11 ms);
                                              # here, not between warm-up and timed region: a collection there idles the device for tens of
                                              # milliseconds and the timed frames then measure its clock ramp (0.54 -> 0.61 ms, measured)
     for i in range(120 * args.prewarm_laps):
