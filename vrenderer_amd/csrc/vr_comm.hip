@@ -60,6 +60,16 @@ int rccl_load()
     return VR_OK;
 }
 
+// The library's own events carry hipEventDisableSystemFence (device-to-device ordering on one GPU).  A collective hands this
+// GPU's buffers to kernels that move them to peer GPUs: in front of it the stream gets ONE event record with the default flags,
+// i.e. a system-scope release of everything the stream has written (a few microseconds on the exchange stream, per collective).
+int system_release(vr_context* ctx)
+{
+    if (!ctx->ev_sysfence) VR_HIP(hipEventCreateWithFlags(&ctx->ev_sysfence, hipEventDisableTiming));
+    VR_HIP(hipEventRecord(ctx->ev_sysfence, ctx->stream));
+    return VR_OK;
+}
+
 int rccl_check(int rc, const char* what)
 {
     if (rc == 0) return VR_OK;
@@ -75,6 +85,7 @@ extern "C" VR_API int vr_frame_allgather(vr_context* ctx, void* nccl_comm, const
     int rc = rccl_load(); if (rc) return rc;
     VR_HIP(hipSetDevice(ctx->device));
     const size_t bytes = vr_partition_packed_bytes(frame_out->w, frame_out->h, world);
+    if ((rc = system_release(ctx))) return rc;
     if ((rc = rccl_check(g_rccl.all_gather(packed, gathered, bytes, kNcclUint8, nccl_comm, ctx->stream), "ncclAllGather"))) return rc;
     return vr_frame_detile(ctx, gathered, world, frame_out);
 }
@@ -84,6 +95,7 @@ extern "C" VR_API int vr_frame_allgather_tiles(vr_context* ctx, void* nccl_comm,
     VR_REQUIRE(ctx && nccl_comm && packed && gathered && world >= 1 && bytes_per_rank > 0, "bad arguments");
     int rc = rccl_load(); if (rc) return rc;
     VR_HIP(hipSetDevice(ctx->device));
+    if ((rc = system_release(ctx))) return rc;
     return rccl_check(g_rccl.all_gather(packed, gathered, bytes_per_rank, kNcclUint8, nccl_comm, ctx->stream), "ncclAllGather");
 }
 
@@ -94,6 +106,7 @@ extern "C" VR_API int vr_frame_allgather_ldr(vr_context* ctx, void* nccl_comm, c
     int rc = rccl_load(); if (rc) return rc;
     VR_HIP(hipSetDevice(ctx->device));
     const size_t bytes = vr_partition_packed_bytes_ldr(w, h, world);
+    if ((rc = system_release(ctx))) return rc;
     if ((rc = rccl_check(g_rccl.all_gather(packed_ldr, gathered, bytes, kNcclUint8, nccl_comm, ctx->stream), "ncclAllGather"))) return rc;
     return vr_frame_detile_ldr(ctx, gathered, world, w, h, ldr_frame);
 }
@@ -105,5 +118,6 @@ extern "C" VR_API int vr_tonemap_allreduce_histogram(vr_tonemap* tm, void* nccl_
     vr_context* ctx = vr_tonemap_context(tm);
     VR_HIP(hipSetDevice(ctx->device));
     void* hist = vr_tonemap_histogram_device_ptr(tm);
+    if ((rc = system_release(ctx))) return rc;
     return rccl_check(g_rccl.all_reduce(hist, hist, VR_TONEMAP_BINS, kNcclUint32, kNcclSum, nccl_comm, ctx->stream), "ncclAllReduce");
 }

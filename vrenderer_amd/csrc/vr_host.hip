@@ -84,6 +84,7 @@ extern "C" VR_API void vr_context_destroy(vr_context* c)
         delete pt;
     }
     timing_reset(c);
+    if (c->ev_sysfence) (void)hipEventDestroy(c->ev_sysfence);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     delete c;

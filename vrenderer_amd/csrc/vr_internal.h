@@ -147,6 +147,7 @@ struct PartTables {
 struct vr_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_sysfence = nullptr;   // the one event WITH a system-scope release (vr_comm.hip: in front of a collective)
     float* d_srgb_lut = nullptr;   // 256 floats: sRGB8 -> linear
     float* d_srgb_thr = nullptr;   // 256 floats: encode thresholds
     float h_srgb_lut[256];
