@@ -565,3 +565,33 @@ def test_shadow_view_and_shadow_term_known_answers(oracle, t256):
     out = oracle.deferred(cam, gb, [sun_oob], AMBIENT_TOP, AMBIENT_BOTTOM, f32=True, shadow=(lv_t, blocked, 0, 0.0))
     far_px = gb.depth > np.quantile(gb.depth[covered], 0.5)
     assert np.array_equal(out[far_px & covered], plain[far_px & covered])
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """`make -C oracle asan` (sanitizers on the CPU build - GPU AddressSanitizer is not available on the pool) and one
+    small frame through the instrumented library: select, raster, pixel shader, lighting, tone map.  `make -C oracle asan-test`
+    runs the whole oracle-driven suites the same way; this keeps the target from rotting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], check=True, capture_output=True, text=True)
+    cc = os.environ.get("CC", "gcc")
+    pre = " ".join(subprocess.run([cc, f"-print-file-name={n}"], capture_output=True, text=True, check=True).stdout.strip()
+                   for n in ("libasan.so", "libubsan.so"))
+    env = dict(os.environ, LD_PRELOAD=pre, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               VR_ORACLE_LIB=os.path.join(root, "oracle", "_build", "libvroracle_asan.so"))
+    code = ("import numpy as np\n"
+            "import vrenderer_amd as vr\n"
+            "from oracle import pyoracle as o\n"
+            "from vrenderer_amd.scene import params, scaled_camera, DEFAULT_EYE, DEFAULT_TARGET, AMBIENT_TOP, AMBIENT_BOTTOM\n"
+            "o.lib()\n"
+            "h = o.synth_heightmap(64); a = o.synth_albedo(64, h)\n"
+            "t = o.OracleTerrain(params(64), h, a)\n"
+            "v = o.view_from_camera(*scaled_camera((DEFAULT_EYE, DEFAULT_TARGET), 64), 96, 54)\n"
+            "gb = o.GBufferHost(96, 54)\n"
+            "n = t.render(v, gb, vr.default_render_params(400.0))\n"
+            "assert n > 0 and (gb.depth < 1.0).any()\n"
+            "print('sanitized frame ok', n)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sanitized frame ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
