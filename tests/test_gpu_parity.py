@@ -856,6 +856,20 @@ def test_scratch_grows_by_high_water_mark_and_reports_sticky_conditions(scene204
     finally:
         tp.close()
     monkeypatch.delenv("VR_SCRATCH_INITIAL_NODES")
+    # 2b. the bins (one entry per triangle and raster tile) grow the same way: too few -> dropped triangles, reported once, then complete
+    monkeypatch.setenv("VR_SCRATCH_INITIAL_BINS", "20000")
+    tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
+    monkeypatch.delenv("VR_SCRATCH_INITIAL_BINS")
+    try:
+        tp.Render(v, v, rt, rp)
+        gpu_ctx.synchronize()
+        assert not np.array_equal(rt.download("depth").view(np.uint32), want.depth.view(np.uint32))
+        rc = gpu_ctx.lib.vr_terrain_render(tp.handle, C.byref(v), C.byref(v), rt.handle, C.byref(rp), None)
+        assert rc == vr.capi.VR_ERR_OVERFLOW
+        _assert_gbuffer_equal(want, planes(rt), "bins grown: the frame queued by the reporting call")
+        assert gpu_ctx.lib.vr_terrain_render(tp.handle, C.byref(v), C.byref(v), rt.handle, C.byref(rp), None) == vr.capi.VR_OK
+    finally:
+        tp.close()
     # 3. defaults: 1024 nodes; worst case on request
     tp = vr.TerrainPass(gpu_ctx, params(2048)).Init(h, a)
     default_bytes = tp.memory_bytes()["scratch"]
@@ -2361,7 +2375,7 @@ def test_tile_pass_launch_order_covers_every_tile_once_longest_bins_first(scene2
     world = part[1] if part else 1
     # the raster tile edge the library picks (vr_internal.h: vr_raster_tile_shift)
     tiles64 = ((w + 63) // 64) * ((h + 63) // 64)
-    edge = 32 if tiles64 // world < 13000 else 64
+    edge = 32                          # (round 4: at every size; tiles64 kept for the record)
     rtx, rty = (w + edge - 1) // edge, (h + edge - 1) // edge
     if part:
         sub = 128 // edge

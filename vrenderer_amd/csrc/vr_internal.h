@@ -42,7 +42,11 @@ constexpr int kRasterTile = 64;              // raster/bin tile (pixels) of larg
 // came from a tile pass that was 40 % slower per pixel and cost N = 2 and N = 4 5-10 %.  With the 32-pixel variants at six waves
 // per SIMD (vr_raster.hip) they win up to ~9.6K x 5.4K: 8K 0.544 vs 0.527 ms, 7040x3960 0.472 vs 0.455, 9600x5400 0.796 vs 0.792,
 // 12288x6912 1.250 vs 1.265 - hence 13000.
-constexpr long kTile64Min = 13000;
+// Round 4: with the plane-state tracking (region states exist on 32-pixel tiles only: vr_gbuffer) and the pre-set-up bin entries
+// 32-pixel tiles win at every size that was measured - 11520x6480 0.902 vs 0.983 ms, 15360x8640 1.589 vs 1.694 (the lighting pass
+// reads what the states let it skip: 324 vs 384 us and 575 vs 683 us; the tile pass itself 560 vs 577 and 996 vs 989 us) - so the
+// rule now picks 32 for any target the library accepts; 64-pixel tiles remain behind VR_OPT_RASTER_TILE.
+constexpr long kTile64Min = 1L << 40;
 // `force`: 0 = the rule above, 5 / 6 = 32- / 64-pixel tiles whatever the size (vr_context_set_option(VR_OPT_RASTER_TILE): tests
 // compare both variants with the oracle at sizes the oracle finishes in seconds; a host may pin the choice)
 inline int vr_raster_tile_shift(int w, int h, int world = 1, int force = 0)
@@ -343,6 +347,7 @@ struct vr_terrain {
     uint32_t* h_status = nullptr;          // kGeoSets x 8 words, hipHostMalloc (mapped)
     uint32_t* d_status = nullptr;          // the device's view of it
     uint32_t high_water = 0;               // most nodes a completed frame selected
+    size_t bin_high_water = 0, bin_want = 0;   // most bin entries a completed frame wanted; the capacity asked for because of it
     int sticky_error = 0;                  // VR_ERR_* of a completed frame, not yet reported
     uint32_t sticky_count = 0;
     GeoSet sets[kGeoSets];

@@ -486,7 +486,10 @@ static int alloc_scratch(vr_terrain* t, int cap)
                     + kSelScratchWords * sizeof(uint32_t) + (size_t)t->hard_cap * (sizeof(uint32_t) + 4 * sizeof(HardTriRec));
     t->bytes_scratch = (uint64_t)fixed * kGeoSets;
     // (triangle, tile) pairs: an 8K frame of ~300 nodes has ~0.3 M, a 1080p frame ~0.6 M; 1 M per 1024 nodes and never fewer
+    // - or what the frames seen so far asked for (a large target on 32-pixel tiles: every triangle lands in more bins)
     t->bin_capacity = ((size_t)1 << 20) * ((mi + 1023) / 1024);
+    if (const char* e = getenv("VR_SCRATCH_INITIAL_BINS")) { const long v = atol(e); if (v >= 1024) t->bin_capacity = (size_t)v; }   // (tests: force the growth path)
+    if (t->bin_want > t->bin_capacity) t->bin_capacity = t->bin_want;
 #define VR_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc(&(ptr), (bytes)); if (e_ != hipSuccess) { \
         vr_set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); return VR_ERR_OUT_OF_MEMORY; } \
         t->bytes_scratch += (uint64_t)(bytes); } while (0)
@@ -513,16 +516,20 @@ int vr_terrain_poll(vr_terrain* t, bool report)
         const volatile uint32_t* st = t->h_status + i * 8;
         const uint32_t flags = st[1], wanted = st[6];
         if (wanted > seen) seen = wanted;
+        if ((size_t)st[5] > t->bin_high_water) t->bin_high_water = (size_t)st[5];     // (triangle, tile) pairs the frame wanted
         if (flags & 1u) { t->sticky_error = VR_ERR_TOO_MANY_INSTANCES; t->sticky_count = wanted; }
         else if (flags & 6u) { if (!t->sticky_error) t->sticky_error = VR_ERR_OVERFLOW; t->sticky_count = wanted; }
     }
     if (seen > t->high_water) t->high_water = seen;
     // grow before a frame can outgrow the scratch: twice the largest count seen, once that passes half the capacity
     const int max_i = t->p.max_instances;
-    if (t->cap_instances < max_i && (size_t)t->high_water * 2 > (size_t)t->cap_instances) {
+    const bool grow_nodes = t->cap_instances < max_i && (size_t)t->high_water * 2 > (size_t)t->cap_instances;
+    const bool grow_bins = t->bin_high_water * 2 > t->bin_capacity;            // (the same rule for the bins: twice what was seen)
+    if (grow_nodes || grow_bins) {
         int want = t->cap_instances;
         while (want < max_i && (size_t)t->high_water * 2 > (size_t)want) want *= 2;
         if (want > max_i) want = max_i;
+        if (grow_bins) { size_t b = t->bin_capacity; while (b < t->bin_high_water * 2) b *= 2; t->bin_want = b; }
         VR_HIP(hipSetDevice(t->ctx->device));
         for (hipStream_t gs : t->geo_streams) VR_HIP(hipStreamSynchronize(gs));
         VR_HIP(hipStreamSynchronize(t->ctx->stream));
@@ -530,8 +537,9 @@ int vr_terrain_poll(vr_terrain* t, bool report)
         int rc = alloc_scratch(t, want);
         if (rc) {
             // the larger scratch does not fit: back to the old size (frames that need more stay truncated and reported)
+            t->bin_want = 0;
             const int rc2 = alloc_scratch(t, had);
-            t->high_water = 0;
+            t->high_water = 0; t->bin_high_water = 0;
             return rc2 ? rc2 : rc;
         }
     }
@@ -681,7 +689,13 @@ static int read_counters(vr_terrain* t, uint32_t* count, bool selection_only = f
     if (count) *count = selection_only ? c[7] : c[0];           // NodeSelect's list is complete up to max_instances whatever the scratch holds
     t->sets[t->cur].status_pending = false;                     // read here; not reported a second time
     if (c[1] & 1u) { vr_set_error("more than max_instances nodes selected (TerrainPass.cpp:238 assert)"); return VR_ERR_TOO_MANY_INSTANCES; }
-    if (c[1] & 2u) { vr_set_error("internal work list overflowed"); return VR_ERR_OVERFLOW; }
+    if ((size_t)c[5] > t->bin_high_water) t->bin_high_water = (size_t)c[5];
+    if (c[1] & 2u) {
+        // a full work list: if it was the bins, they grow now (twice what this frame wanted) and rendering the frame again is complete
+        (void)vr_terrain_poll(t, false);
+        vr_set_error("internal work list overflowed (the frame wanted %u bin entries; the bins now hold %zu)", c[5], t->bin_capacity);
+        return VR_ERR_OVERFLOW;
+    }
     if (c[1] & 4u) {
         // the frame wanted more nodes than the scratch held: grow now, so that rendering the frame again is complete
         if (c[6] > t->high_water) t->high_water = c[6];
