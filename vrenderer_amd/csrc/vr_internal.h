@@ -384,6 +384,7 @@ int vr_terrain_pick_set(vr_terrain* t);
 // reads the counters of completed chains (no wait), grows the scratch by the high-water mark; returns a completed frame's sticky
 // device-side error once (VR_OK otherwise).  Called at the head of vr_terrain_render / vr_terrain_prepare / vr_terrain_select.
 int vr_terrain_poll(vr_terrain* t, bool report);
+int vr_terrain_reserve_bins(vr_terrain* t, size_t tiles);     // room for a target of that many raster tiles (vr_select.hip)
 // tables of (w, h, part); part == NULL is the whole frame as rank 0 of 1
 int vr_partition_tables(vr_context* ctx, int w, int h, const vr_partition* part, const PartTables** out);
 // any cached table set of (w, h, world): the slot table does not depend on the rank

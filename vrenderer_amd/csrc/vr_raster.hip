@@ -1887,6 +1887,8 @@ extern "C" VR_API int vr_terrain_prepare(vr_terrain* t, const vr_view* view, vr_
     if ((rc = vr_terrain_poll(t, false))) return rc;
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
+    if ((rc = vr_terrain_reserve_bins(t, (size_t)a.rtx * a.rty / (size_t)(a.world > 1 ? a.world : 1)))) return rc;
+    a.bin_capacity = (uint32_t)t->bin_capacity;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
     if (a.world > 1 && (rc = vr_partition_tables(t->ctx, gb->w, gb->h, part, &pt))) return rc;
     // already prepared for exactly these inputs (a caller may name the same future frame twice): nothing to do
@@ -1970,6 +1972,8 @@ static int terrain_render_impl(vr_terrain* t, const vr_view* view, vr_gbuffer* g
     if (earlier && earlier != VR_ERR_OVERFLOW && earlier != VR_ERR_TOO_MANY_INSTANCES) return earlier;     // (the scratch could not grow)
     RasterArgs a;
     if ((rc = make_raster_args(t, view, rp, gb->w, gb->h, part, a))) return rc;
+    if ((rc = vr_terrain_reserve_bins(t, (size_t)a.rtx * a.rty / (size_t)(a.world > 1 ? a.world : 1)))) return rc;
+    a.bin_capacity = (uint32_t)t->bin_capacity;
     const PartTables* pt = nullptr;       // this rank's raster tiles; unused (NULL) for the whole frame
     if (a.world > 1 && (rc = vr_partition_tables(ctx, gb->w, gb->h, part, &pt))) return rc;
     // RenderTargets::Clear is lazy under the plane-state tracking (vr_gbuffer::clear_pending): a shaded pass over the whole frame
