@@ -155,6 +155,8 @@ def main():
                     help="opt-in fused variant (vr_terrain_render_lit, SURVEY 7 step 6): the tile pass shades what it rasterises and writes depth + "
                          "HdrColor only - same bits as the two passes; reported as the `fused` sub-record of the default run, never as the headline")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second timed region (the same K frames after one more lap of load)")
+    ap.add_argument("--no-plane-tracking", action="store_true",
+                    help="the whole run with vr_context_set_option(VR_OPT_PLANE_TRACKING, 0): every plane of every pixel written and read")
     ap.add_argument("--timing-level", type=int, default=2, choices=[0, 1, 2],
                     help="vr_timing_enable level inside the timed region: 2 = dispatch-stamped events on the two big kernels (default), "
                          "1 = event records around every kernel, 0 = none (no per-kernel figures; measures what the stamps cost)")
@@ -258,6 +260,8 @@ def main():
 
     if args.no_dispatch_events:
         ctx.set_dispatch_events(False)
+    if args.no_plane_tracking:
+        ctx.set_plane_tracking(False)
     hm = vr.synth_heightmap(ctx, size, 1337)
     al = vr.synth_albedo(ctx, size, hm, 4242)
     tp = vr.TerrainPass(ctx, params(size)).Init(hm, al)
@@ -581,7 +585,7 @@ def main():
     # every pixel and the lighting pass reads them all, as a renderer without clear / constant metadata would.  Same frames, same
     # bits in the G-buffer and in HdrColor; reported beside `value` so that the tracking's share of it is on the page.
     untracked = None
-    if not args.no_sustained and not args.fused:
+    if not args.no_sustained and not args.fused and not args.no_plane_tracking:
         ctx.set_plane_tracking(False)
         gc.collect(); gc.disable()
         for i in range(20):

@@ -55,6 +55,71 @@ __device__ __forceinline__ void store_quad(uint2* __restrict__ out, size_t out_i
 #ifndef VR_DEFERRED_WAVES
 #define VR_DEFERRED_WAVES 4
 #endif
+// The lighting pass as a pure stream: every plane of every pixel read, nothing known about any of them (the plane-state tracking is
+// off, or the host holds the planes' pointers).  Round 3's kernel, kept as it was: with all seven loads in flight per lane and the
+// table's barrier in front of them it moves the 36 B/px at 5.7 TB/s; the variant below, which asks first what it need not read,
+// costs that case 10 us (221 vs 210 us at 8K).
+template <bool PACKED, bool EXTRA, bool SHADOW = false, bool NT = false>
+__global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred_stream(DeferredArgs a, const float* __restrict__ g_depth,
+                                                   const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
+                                                   const uint2* __restrict__ g_nrm, const uint2* __restrict__ g_emi,
+                                                   uint2* __restrict__ out, const float* __restrict__ lut_g,
+                                                   const int32_t* __restrict__ owned_tiles, ShadowArgs sh)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+
+    int px0, py;          // first pixel of this lane's quad
+    size_t out_index;     // in pixels
+    if (PACKED) {
+        const int lt = blockIdx.x >> 4, rg = blockIdx.x & 15;
+        const int tile = owned_tiles[lt];
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int row = rg * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 4;
+        px0 = tx * VR_OWNER_TILE + col; py = ty * VR_OWNER_TILE + row;
+        out_index = ((size_t)lt * VR_OWNER_TILE + row) * VR_OWNER_TILE + col;
+        if (px0 >= a.w || py >= a.h) return;
+    } else {
+        const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t p = q * 4;
+        if (p >= (size_t)a.w * a.h) return;
+        py = (int)(p / (size_t)a.w); px0 = (int)(p - (size_t)py * a.w);
+        out_index = p;
+    }
+    const size_t p = (size_t)py * a.w + px0;
+    // issue every load first: 7 x 16 B per lane in flight
+    // NT: streaming (non-temporal) G-buffer reads - together with the streaming stores (store_quad) the frame's 1.2 GB then
+    // pass the caches by and the tile pass's texel tables (180 MB) are still in the Infinity Cache when the next frame's
+    // tile pass starts.  Either one alone does not help: 929 MB of reads or 265 MB of dirty lines each flush the cache.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LD16(ptr) ({ u32x4 v_; if (NT) v_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr)); else v_ = *reinterpret_cast<const u32x4*>(ptr); \
+                     make_uint4(v_.x, v_.y, v_.z, v_.w); })
+    const uint4 dzu = LD16(g_depth + p);
+    const float4 dz = make_float4(__uint_as_float(dzu.x), __uint_as_float(dzu.y), __uint_as_float(dzu.z), __uint_as_float(dzu.w));
+    const uint4 df = LD16(g_diff + p);
+    const uint4 sp = LD16(g_spec + p);
+    const uint4 n0 = LD16(g_nrm + p);
+    const uint4 n1 = LD16(g_nrm + p + 2);
+    const uint4 e0 = LD16(g_emi + p);
+    const uint4 e1 = LD16(g_emi + p + 2);
+#undef LD16
+
+    const float depth[4] = { dz.x, dz.y, dz.z, dz.w };
+    const uint32_t dfa[4] = { df.x, df.y, df.z, df.w }, spa[4] = { sp.x, sp.y, sp.z, sp.w };
+    const uint32_t na[8] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w };
+    const uint32_t ea[8] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w };
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float rgb[3];
+        shade_pixel<EXTRA, SHADOW>(a, lut, px0 + k, py, depth[k], dfa[k], spa[k], na[2 * k], na[2 * k + 1], ea[2 * k], ea[2 * k + 1], rgb, &sh);
+        o[2 * k] = vr_float_to_half(rgb[0]) | (vr_float_to_half(rgb[1]) << 16);
+        o[2 * k + 1] = vr_float_to_half(rgb[2]);          // alpha = 0
+    }
+    store_quad<PACKED, NT>(out, out_index, o);
+}
+
 template <bool PACKED, bool EXTRA, bool SHADOW = false, bool NT = false>
 __global__ __launch_bounds__(256, VR_DEFERRED_WAVES) void k_deferred(DeferredArgs a, const float* __restrict__ g_depth,
                                                    const uint32_t* __restrict__ g_diff, const uint32_t* __restrict__ g_spec,
@@ -231,6 +296,7 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
     const bool packed = part != nullptr;     // a partition (even of one rank) selects the packed tile-major output
     PlaneHints hints;
     { int rc = vr_gbuffer_plane_hints(gb, ctx->stream, &hints); if (rc) return rc; }
+    const bool hinted = hints.region != nullptr || hints.emissive_zero != 0;       // else: the pure-stream kernel
     VrKernelScope ks(ctx, VR_K_DEFERRED, ctx->stream, true);
     if (packed) {
         const PartTables* pt = nullptr;
@@ -241,9 +307,15 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
         VR_REQUIRE(gb->w % 4 == 0, "partitioned frames need a width that is a multiple of 4");
         a.tiles_x = (gb->w + VR_OWNER_TILE - 1) / VR_OWNER_TILE;
         if (pt->num_owned > 0) {
+            if (!hinted) {
+                auto kern = shadow ? k_deferred_stream<true, true, true> : (extra ? k_deferred_stream<true, true> : k_deferred_stream<true, false>);
+                VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)pt->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
+                                   gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, pt->d_owned_tiles, sh);
+            } else {
             auto kern = shadow ? k_deferred<true, true, true> : (extra ? k_deferred<true, true> : k_deferred<true, false>);
             VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)pt->num_owned * 16), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, pt->d_owned_tiles, sh, hints);
+            }
         }
     } else {
         VR_REQUIRE(npx * 8 <= hdr->capacity_bytes, "hdr_out is smaller than the frame");
@@ -251,11 +323,18 @@ static int deferred_light(vr_context* ctx, const vr_view* view, vr_gbuffer* gb, 
             const size_t quads = npx / 4;
             // streaming loads and stores at every frame size, like the tile pass's stores (vr_raster.hip: measured per size)
             const bool nt = true;
+            if (!hinted) {
+                auto kern = shadow ? k_deferred_stream<false, true, true, true> : extra ? k_deferred_stream<false, true, false, true>
+                                                                                        : k_deferred_stream<false, false, false, true>;
+                VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
+                                   gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh);
+            } else {
             auto kern = shadow ? (nt ? k_deferred<false, true, true, true> : k_deferred<false, true, true, false>)
                                : extra ? (nt ? k_deferred<false, true, false, true> : k_deferred<false, true, false, false>)
                                        : (nt ? k_deferred<false, false, false, true> : k_deferred<false, false, false, false>);
             VR_LAUNCH_TIMED(ks, kern, dim3((unsigned)((quads + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, (const int32_t*)nullptr, sh, hints);
+            }
         } else {
             VR_LAUNCH_TIMED(ks, k_deferred_scalar, dim3((unsigned)((npx + 255) / 256)), dim3(256), ctx->stream, a, gb->depth, gb->diffuse,
                                gb->specular, gb->normals, gb->emissive, (uint2*)hdr->data, ctx->d_srgb_lut, sh, shadow ? 1 : 0);
