@@ -945,6 +945,21 @@ def main():
                                       "note": "not bandwidth-bound (SURVEY 7): 1.6 lights reach a covered pixel on average, ~85 instructions each"}
             except Exception as e:
                 out["lights_1024"] = {"error": repr(e)}
+        if world == 1 and not use_dist and not emu and (W, H) == (7680, 4320) and not args.no_4k and not args.shadows and not tiled and not args.fused:
+            # row f1 (Renderer.cpp:333-372, :427): the same frame with the sun's terrain shadow map (2048^2, depth-only pass per frame)
+            # and the 4x4 PCF term in the lighting pass (child process)
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shadows", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--no-cpu-baseline", "--no-4k"] + (["--fixed-camera"] if args.fixed_camera else []),
+                                   capture_output=True, text=True, timeout=300)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["shadows"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                                  "sustained": (j.get("sustained") or {}).get("value"),
+                                  "kernels": {k: v["avg_us"] for k, v in j["kernels"].items() if k in ("k_raster", "k_raster (depth only)", "k_deferred")},
+                                  "note": "terrain shadow pass (depth only, 2048^2) + shadowed lighting pass (sixteen PCF taps per pixel) in every frame"}
+            except Exception as e:
+                out["shadows"] = {"error": repr(e)}
         if args.fused:
             out["config"]["workload"] += "; FUSED variant (vr_terrain_render_lit): lighting inside the tile pass, depth + HdrColor written (12 B/px)"
             out["roofline"] = None
